@@ -1,0 +1,287 @@
+"""Communication layer: one process per GPU, ``torch.distributed`` over RCCL (xGMI).
+
+Reference: the scripts call ``dist.init_process_group`` with a TCP url
+(multinode-DP/multinodeDP.py:159-162, multinode-MP/multinodeMP.py:172-178), use one
+blocking ``all_reduce`` per parameter (DP.py:126-129) and blocking CPU-staged
+``send``/``recv`` (MP.py:140,144,153,167).  Here:
+
+* backend ``rccl`` (an alias of c10d's ``nccl``, which *is* RCCL on ROCm) moves
+  device buffers directly - no host staging; ``gloo`` is the CPU loopback backend
+  used for tests and for BASELINE config 1.
+* collectives are issued asynchronously on RCCL's own stream; ordering against the
+  compute stream is done by c10d's event record/wait, so the caller overlaps them
+  with backward and only waits on the handle before the optimizer.
+* sub-groups (DP group per pipeline stage, PP group per replica) for the hybrid.
+* a debug mode (``DPA_SYNC_DEBUG=1``) that synchronises after every op so stream
+  ordering bugs become deterministic failures.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+_SYNC_DEBUG = os.environ.get("DPA_SYNC_DEBUG", "0") == "1"
+
+
+def set_sync_debug(flag: bool) -> None:
+    global _SYNC_DEBUG
+    _SYNC_DEBUG = bool(flag)
+
+
+def resolve_backend(backend: str, device: Optional[torch.device] = None) -> str:
+    b = (backend or "auto").lower()
+    if b == "auto":
+        use_gpu = torch.cuda.is_available() if device is None else device.type == "cuda"
+        return "nccl" if use_gpu else "gloo"
+    if b in ("rccl", "nccl"):
+        return "nccl"
+    if b == "gloo":
+        return "gloo"
+    raise ValueError(f"unknown backend {backend!r} (use auto|rccl|nccl|gloo)")
+
+
+def rccl_env_defaults() -> None:
+    """Environment for RCCL over the 8-GPU xGMI mesh.  Only sets defaults.
+
+    Each MI355X has 7 point-to-point xGMI links (one per peer); more channels let
+    RCCL drive several links at once instead of a single ring pair.
+    """
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("NCCL_MIN_NCHANNELS", "32")
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+
+
+def init_process_group(backend: str = "auto", init_method: Optional[str] = None, rank: Optional[int] = None,
+                       world_size: Optional[int] = None, timeout_s: float = 300.0,
+                       device: Optional[torch.device] = None) -> "Communicator":
+    """Rendezvous + communicator creation.
+
+    ``init_method`` is the reference's ``tcp://MASTER:PORT`` url; when omitted the
+    ``MASTER_ADDR``/``MASTER_PORT``/``RANK``/``WORLD_SIZE`` environment is used
+    (that is what torchrun / bench.py export).
+    """
+    be = resolve_backend(backend, device)
+    if be == "nccl":
+        rccl_env_defaults()
+    kwargs = dict(backend=be, timeout=datetime.timedelta(seconds=timeout_s))
+    if init_method is not None and init_method != "env://":
+        kwargs.update(init_method=init_method, rank=rank, world_size=world_size)
+        # keep env in step so libraries that read it agree (MP.py:175-176 does the same)
+        hostport = init_method.split("://", 1)[-1]
+        if ":" in hostport:
+            host, port = hostport.rsplit(":", 1)
+            os.environ.setdefault("MASTER_ADDR", host)
+            os.environ.setdefault("MASTER_PORT", port)
+    else:
+        if rank is not None:
+            os.environ.setdefault("RANK", str(rank))
+        if world_size is not None:
+            os.environ.setdefault("WORLD_SIZE", str(world_size))
+    if be == "nccl" and device is not None and device.type == "cuda":
+        kwargs["device_id"] = device
+    if not dist.is_initialized():
+        dist.init_process_group(**kwargs)
+    return Communicator(group=None, device=device)
+
+
+def destroy_process_group() -> None:
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def get_rank() -> int:
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def get_world_size() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+class _DoneWork:
+    """Stand-in handle for world_size == 1 / already-finished ops."""
+    def wait(self):
+        return True
+
+    def is_completed(self):
+        return True
+
+
+class Communicator:
+    """Thin, group-scoped view of the process group.
+
+    All tensor arguments are used in place.  With the RCCL backend they are device
+    buffers and nothing is staged through the host.
+    """
+
+    def __init__(self, group=None, device: Optional[torch.device] = None, ranks: Optional[Sequence[int]] = None):
+        self.group = group
+        self.device = device
+        self._ranks = list(ranks) if ranks is not None else None
+        self.initialized = dist.is_initialized()
+
+    # ---- queries (reference: dist.get_rank / get_world_size, DP.py:108,112) ----
+    @property
+    def rank(self) -> int:
+        return dist.get_rank(self.group) if self.initialized else 0
+
+    @property
+    def world_size(self) -> int:
+        return dist.get_world_size(self.group) if self.initialized else 1
+
+    @property
+    def global_rank(self) -> int:
+        return dist.get_rank() if self.initialized else 0
+
+    @property
+    def backend(self) -> str:
+        return dist.get_backend(self.group) if self.initialized else "none"
+
+    def to_global(self, group_rank: int) -> int:
+        if self._ranks is None:
+            return group_rank
+        return self._ranks[group_rank]
+
+    # ---- collectives ----
+    def all_reduce(self, tensor: torch.Tensor, op=dist.ReduceOp.SUM, async_op: bool = False):
+        if self.world_size == 1:
+            return _DoneWork() if async_op else None
+        work = dist.all_reduce(tensor, op=op, group=self.group, async_op=True)
+        if _SYNC_DEBUG:
+            work.wait()
+            if tensor.is_cuda:
+                torch.cuda.synchronize(tensor.device)
+        if async_op:
+            return work
+        work.wait()
+        return None
+
+    def reduce_scatter(self, output: torch.Tensor, input: torch.Tensor, async_op: bool = False):
+        if self.world_size == 1:
+            output.copy_(input)
+            return _DoneWork() if async_op else None
+        work = dist.reduce_scatter_tensor(output, input, group=self.group, async_op=True)
+        if async_op and not _SYNC_DEBUG:
+            return work
+        work.wait()
+        return _DoneWork() if async_op else None
+
+    def all_gather(self, output: torch.Tensor, input: torch.Tensor, async_op: bool = False):
+        if self.world_size == 1:
+            output.copy_(input)
+            return _DoneWork() if async_op else None
+        work = dist.all_gather_into_tensor(output, input, group=self.group, async_op=True)
+        if async_op and not _SYNC_DEBUG:
+            return work
+        work.wait()
+        return _DoneWork() if async_op else None
+
+    def broadcast(self, tensor: torch.Tensor, src: int = 0, async_op: bool = False):
+        if self.world_size == 1:
+            return _DoneWork() if async_op else None
+        work = dist.broadcast(tensor, src=self.to_global(src), group=self.group, async_op=True)
+        if async_op and not _SYNC_DEBUG:
+            return work
+        work.wait()
+        return _DoneWork() if async_op else None
+
+    def barrier(self):
+        if self.world_size > 1:
+            if self.backend == "nccl" and self.device is not None:
+                dist.barrier(group=self.group, device_ids=[self.device.index])
+            else:
+                dist.barrier(group=self.group)
+
+    # ---- point to point (reference: MP.py:140,144,153,167) ----
+    def send(self, tensor: torch.Tensor, dst: int):
+        dist.send(tensor, dst=self.to_global(dst), group=self.group)
+        if _SYNC_DEBUG and tensor.is_cuda:
+            torch.cuda.synchronize(tensor.device)
+
+    def recv(self, tensor: torch.Tensor, src: int):
+        dist.recv(tensor, src=self.to_global(src), group=self.group)
+        if _SYNC_DEBUG and tensor.is_cuda:
+            torch.cuda.synchronize(tensor.device)
+
+    def isend(self, tensor: torch.Tensor, dst: int):
+        return dist.isend(tensor, dst=self.to_global(dst), group=self.group)
+
+    def irecv(self, tensor: torch.Tensor, src: int):
+        return dist.irecv(tensor, src=self.to_global(src), group=self.group)
+
+    def batch_p2p(self, ops: List[tuple]):
+        """``ops`` = [("send"|"recv", tensor, peer), ...] issued as one grouped RCCL
+        call (ncclGroupStart/End) so a send and a recv to neighbours cannot deadlock."""
+        if not ops:
+            return []
+        p2p = []
+        for kind, tensor, peer in ops:
+            fn = dist.isend if kind == "send" else dist.irecv
+            p2p.append(dist.P2POp(fn, tensor, self.to_global(peer), self.group))
+        works = dist.batch_isend_irecv(p2p)
+        if _SYNC_DEBUG:
+            for w in works:
+                w.wait()
+        return works
+
+    # ---- object helpers (cold path: checkpoint merge, metrics) ----
+    def gather_object(self, obj, dst: int = 0):
+        if self.world_size == 1:
+            return [obj]
+        out = [None] * self.world_size if self.rank == dst else None
+        dist.gather_object(obj, out, dst=self.to_global(dst), group=self.group)
+        return out
+
+    def broadcast_object(self, obj, src: int = 0):
+        if self.world_size == 1:
+            return obj
+        box = [obj]
+        dist.broadcast_object_list(box, src=self.to_global(src), group=self.group)
+        return box[0]
+
+    def all_reduce_scalar(self, value: float, op: str = "sum") -> float:
+        if self.world_size == 1:
+            return float(value)
+        dev = self.device if (self.device is not None and self.backend == "nccl") else torch.device("cpu")
+        t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        rop = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op]
+        dist.all_reduce(t, op=rop, group=self.group)
+        return float(t.item())
+
+    # ---- sub-groups ----
+    def split(self, ranks: Sequence[int]) -> Optional["Communicator"]:
+        """Collective over the *world*: every rank must call ``split`` with the same
+        sequence of rank lists, in the same order.  Returns the communicator when
+        this rank is a member, else None."""
+        ranks = list(ranks)
+        group = dist.new_group(ranks=ranks)
+        if dist.get_rank() in ranks:
+            return Communicator(group=group, device=self.device, ranks=ranks)
+        return None
+
+
+def build_grid(world: Communicator, dp: int, pp: int):
+    """DP x PP process grid.  Rank layout: ``rank = replica * pp + stage`` so the
+    stages of one pipeline replica are adjacent GPUs.  Returns
+    ``(pp_comm, dp_comm, replica, stage)``; ``pp_comm`` spans the stages of this
+    replica, ``dp_comm`` spans the replicas of this stage."""
+    n = world.world_size
+    if dp * pp != n:
+        raise ValueError(f"dp({dp}) x pp({pp}) != world size {n}")
+    me = world.global_rank
+    replica, stage = divmod(me, pp)
+    pp_comm = dp_comm = None
+    if n == 1:
+        return world, world, 0, 0
+    for r in range(dp):
+        c = world.split([r * pp + s for s in range(pp)])
+        if r == replica:
+            pp_comm = c
+    for s in range(pp):
+        c = world.split([r * pp + s for r in range(dp)])
+        if s == stage:
+            dp_comm = c
+    return pp_comm, dp_comm, replica, stage

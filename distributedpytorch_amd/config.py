@@ -1,0 +1,185 @@
+"""Flag / config system.
+
+Keeps the flag *names* of the reference scripts so a user can switch launch lines
+unchanged (reference: multinode-DP/multinodeDP.py:24-40 and
+multinode-MP/multinodeMP.py:20-40), but every flag is real here: ``--epochs``,
+``--lr``, ``--momentum`` and ``--seed`` are honoured instead of being hard-coded
+(the reference ignores ``--epochs`` and hard-codes 10 / 100 epochs, DP.py:146,
+MP.py:126).  The parsed result is a picklable dataclass that is handed to the
+children explicitly, so the *spawn* start method works (the reference relies on
+``fork`` + a module global, DP.py:166).
+"""
+from __future__ import annotations
+
+import argparse
+from dataclasses import dataclass, field, asdict
+from typing import List, Optional, Sequence
+
+
+def parse_gpu_list(text) -> List[int]:
+    """``"4,4"`` -> ``[4, 4]``.  Accepts an int / list as well (the reference's
+    default is the int 0, which crashes on ``.split`` - DP.py:37,171)."""
+    if isinstance(text, (list, tuple)):
+        out = [int(v) for v in text]
+    elif isinstance(text, int):
+        out = [text]
+    else:
+        out = [int(item) for item in str(text).split(",") if item.strip() != ""]
+    if not out or any(v < 0 for v in out) or sum(out) == 0:
+        raise ValueError(f"--GPU-list must name at least one process, got {text!r}")
+    return out
+
+
+def normalize_dist_url(url: str) -> str:
+    """The reference's default ``127.0.0.1:8885`` has no scheme and is rejected by
+    c10d (DP.py:27); accept it and add ``tcp://``."""
+    if "://" not in url:
+        return "tcp://" + url
+    return url
+
+
+@dataclass
+class TrainConfig:
+    # ---- topology (reference flags) ----
+    gpu_list: List[int] = field(default_factory=lambda: [1])
+    node_index: int = 0
+    backend: str = "auto"          # auto -> rccl when GPUs are visible else gloo
+    dist_url: str = "tcp://127.0.0.1:8885"
+    # ---- training ----
+    epochs: int = 10
+    batch_size: int = 128          # DP: global batch (DP.py:109); MP: per-step batch (MP.py:35)
+    lr: float = 0.01
+    momentum: float = 0.5
+    weight_decay: float = 0.0
+    seed: int = 1234
+    workers: int = 0
+    # ---- model / data ----
+    model: str = "mnist_cnn"
+    dataset: str = "synthetic"
+    dataset_size: int = 60000
+    dtype: str = "auto"            # auto: bf16 on GPU for big models, fp32 for the MNIST nets
+    # ---- engine ----
+    bucket_mb: float = 32.0
+    first_bucket_mb: float = 4.0
+    micro_batches: int = 1
+    schedule: str = "1f1b"
+    stages: int = 2
+    dp_replicas: int = 1
+    steps_per_epoch: Optional[int] = None
+    checkpoint: Optional[str] = None
+    resume: Optional[str] = None
+    log_json: Optional[str] = None
+    timeout_s: float = 300.0
+    sync_debug: bool = False
+    device: str = "auto"           # auto | cuda | cpu
+
+    # -------- derived topology (reference: DP.py:170-174) --------
+    @property
+    def local_size(self) -> int:
+        return self.gpu_list[self.node_index]
+
+    @property
+    def world_size(self) -> int:
+        return sum(self.gpu_list)
+
+    @property
+    def rank_offset(self) -> int:
+        return sum(self.gpu_list[: self.node_index])
+
+    def to_dict(self):
+        return asdict(self)
+
+
+def _common_flags(p: argparse.ArgumentParser) -> None:
+    # Reference flags (kept verbatim so launch lines carry over).
+    p.add_argument("--workers", default=0, type=int, metavar="N",
+                   help="data loading workers (synthetic data needs none)")
+    p.add_argument("--gpu", default=None, type=int, help="accepted for compatibility; device = local rank")
+    p.add_argument("--rank", default=0, type=int, help="accepted for compatibility; rank comes from --GPU-list/--node-index")
+    p.add_argument("--epochs", default=None, type=int, help="number of epochs (honoured, unlike the reference)")
+    p.add_argument("--backend", default="auto", type=str, help="auto | rccl | nccl | gloo")
+    p.add_argument("--GPU-list", default="1", type=str,
+                   help="processes per node, e.g. --GPU-list=4,4 (heterogeneous lists such as 4,2,1 work)")
+    p.add_argument("--node-index", default=0, type=int, help="index of this node inside --GPU-list")
+    # New, real hyper-parameters.
+    p.add_argument("--lr", default=None, type=float)
+    p.add_argument("--momentum", default=None, type=float)
+    p.add_argument("--weight-decay", default=0.0, type=float)
+    p.add_argument("--seed", default=1234, type=int)
+    p.add_argument("--model", default=None, type=str)
+    p.add_argument("--dataset-size", default=60000, type=int)
+    p.add_argument("--steps-per-epoch", default=None, type=int)
+    p.add_argument("--dtype", default="auto", type=str)
+    p.add_argument("--device", default="auto", type=str)
+    p.add_argument("--checkpoint", default=None, type=str, help="path to write a state_dict checkpoint")
+    p.add_argument("--resume", default=None, type=str, help="path of a checkpoint to resume from")
+    p.add_argument("--log-json", default=None, type=str, help="append JSON-lines metrics to this file")
+    p.add_argument("--timeout", default=300.0, type=float, help="rendezvous / collective timeout in seconds")
+    p.add_argument("--sync-debug", action="store_true", help="synchronise after every comm op and check grads")
+
+
+def dp_parser() -> argparse.ArgumentParser:
+    """Parser for the data-parallel example (reference: DP.py:24-40)."""
+    p = argparse.ArgumentParser(description="MI355X data-parallel training")
+    _common_flags(p)
+    p.add_argument("--dist-url", default="tcp://127.0.0.1:8885", type=str,
+                   help="rendezvous url; a bare host:port is accepted")
+    p.add_argument("--batch-size", default=128, type=int, help="GLOBAL batch (reference fixes 128, DP.py:109)")
+    p.add_argument("--bucket-mb", default=32.0, type=float)
+    p.add_argument("--first-bucket-mb", default=4.0, type=float)
+    return p
+
+
+def mp_parser() -> argparse.ArgumentParser:
+    """Parser for the model-parallel example (reference: MP.py:20-40)."""
+    p = argparse.ArgumentParser(description="MI355X model-parallel (pipeline) training")
+    _common_flags(p)
+    p.add_argument("--batch-size", default=1024, type=int, help="batch size per step (MP.py:35)")
+    p.add_argument("--IP", default="127.0.0.1", type=str, help="master address")
+    p.add_argument("--portNum", default="39990", type=str, help="master port")
+    p.add_argument("--micro-batches", default=1, type=int, help="1 reproduces the reference's serial schedule")
+    p.add_argument("--schedule", default="1f1b", choices=["serial", "gpipe", "1f1b"])
+    p.add_argument("--stages", default=2, type=int)
+    p.add_argument("--dp-replicas", default=1, type=int, help="pipeline replicas (DP x PP hybrid)")
+    return p
+
+
+def config_from_args(args: argparse.Namespace, mode: str) -> TrainConfig:
+    gpu_list = parse_gpu_list(args.GPU_list)
+    if not 0 <= args.node_index < len(gpu_list):
+        raise ValueError(f"--node-index {args.node_index} outside --GPU-list {gpu_list}")
+    if mode == "dp":
+        url = normalize_dist_url(args.dist_url)
+        defaults = dict(epochs=10, lr=0.01, momentum=0.5, model="mnist_cnn")
+    else:
+        url = f"tcp://{args.IP}:{args.portNum}"
+        defaults = dict(epochs=100, lr=0.01, momentum=0.0, model="mnist_cnn")
+    cfg = TrainConfig(
+        gpu_list=gpu_list, node_index=args.node_index, backend=args.backend, dist_url=url,
+        epochs=args.epochs if args.epochs is not None else defaults["epochs"],
+        batch_size=args.batch_size,
+        lr=args.lr if args.lr is not None else defaults["lr"],
+        momentum=args.momentum if args.momentum is not None else defaults["momentum"],
+        weight_decay=args.weight_decay, seed=args.seed, workers=args.workers,
+        model=args.model or defaults["model"], dataset_size=args.dataset_size,
+        steps_per_epoch=args.steps_per_epoch, dtype=args.dtype, device=args.device,
+        checkpoint=args.checkpoint, resume=args.resume, log_json=args.log_json,
+        timeout_s=args.timeout, sync_debug=args.sync_debug,
+    )
+    if mode == "dp":
+        cfg.bucket_mb = args.bucket_mb
+        cfg.first_bucket_mb = args.first_bucket_mb
+    else:
+        cfg.micro_batches = args.micro_batches
+        cfg.schedule = args.schedule
+        cfg.stages = args.stages
+        cfg.dp_replicas = args.dp_replicas
+    return cfg
+
+
+def parse_dp(argv: Optional[Sequence[str]] = None) -> TrainConfig:
+    return config_from_args(dp_parser().parse_args(argv), "dp")
+
+
+def parse_mp(argv: Optional[Sequence[str]] = None) -> TrainConfig:
+    return config_from_args(mp_parser().parse_args(argv), "mp")

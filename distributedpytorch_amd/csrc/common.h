@@ -1,0 +1,76 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) kernels.
+// Wave = 64 lanes; MFMA bf16 tiles 16x16x32 / 32x32x16; LDS 160 KiB per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dpa {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(4))) float floatx4;
+typedef __attribute__((ext_vector_type(16))) float floatx16;
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float bf16_to_float(unsigned short v) {
+    return __builtin_bit_cast(float, ((unsigned int)v) << 16);
+}
+
+// Round-to-nearest-even via a plain cast: hipcc emits v_cvt_pk_bf16_f32, which
+// keeps NaN a NaN (integer-trick rounding does not).
+__device__ __forceinline__ unsigned short float_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    return (unsigned int)float_to_bf16(lo) | ((unsigned int)float_to_bf16(hi) << 16);
+}
+
+// 8 bf16 packed in a uint4 <-> 8 floats
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+    f[0] = bf16_to_float(v.x & 0xffff); f[1] = bf16_to_float(v.x >> 16);
+    f[2] = bf16_to_float(v.y & 0xffff); f[3] = bf16_to_float(v.y >> 16);
+    f[4] = bf16_to_float(v.z & 0xffff); f[5] = bf16_to_float(v.z >> 16);
+    f[6] = bf16_to_float(v.w & 0xffff); f[7] = bf16_to_float(v.w >> 16);
+}
+
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    uint4 v;
+    v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+    v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+    return v;
+}
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float x2 = x * x;
+    float u = k0 * (x + k1 * x * x2);
+    float t = tanhf(u);
+    float du = k0 * (1.0f + 3.0f * k1 * x2);
+    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace dpa

@@ -1,0 +1,334 @@
+// Implicit-GEMM convolution (fprop + dgrad) for gfx950: NHWC bf16 activations,
+// KRSC bf16 filters, fp32 accumulation on v_mfma_f32_16x16x32_bf16.
+//
+// GEMM view (per output pixel p = (n,ho,wo) and output channel k):
+//     y[p][k] = sum_{kk} im2col(x)[p][kk] * w[k][kk],   kk = (r,s,c), c fastest
+// Both operands are K-contiguous, which is exactly the bf16 MFMA fragment shape
+// (8 consecutive k per lane), so no transposes are needed.  The MFMA A operand is
+// the FILTER tile (rows = output channels) and the B operand the gathered
+// activation tile (cols = pixels): each lane then holds 4 consecutive output
+// channels of one pixel, i.e. 8 contiguous bytes of the NHWC output row.
+//
+// Block = 4 waves (64-wide), each wave a 64(pixel) x 64(channel) tile as 4x4 MFMA
+// tiles; block tile 128x128 (2x2 waves) or 256x64 (4x1 waves, for 64-channel
+// layers).  K step 32.  Register-staged double-buffered LDS (issue-early /
+// write-late, one barrier per K step); LDS tiles XOR-swizzled so the ds_read_b128
+// fragment reads are bank-conflict free.  Epilogue goes through LDS so that global
+// stores are 16 B per lane over full NHWC rows, and optionally emits per-channel
+// (sum, sum of squares) partials for a following BatchNorm, which removes one
+// full read of the activation tensor per layer.
+#include "common.h"
+#include "kernels.h"
+
+namespace dpa {
+
+namespace {
+
+constexpr int BK = 32;          // K step (bf16 elements)
+constexpr int CHUNKS = BK / 8;  // 16-byte chunks per tile row
+
+__device__ __forceinline__ int swz4(int row) {  // conflict-free chunk swizzle for 64-byte rows
+    return (0x78 >> (2 * ((row >> 2) & 3))) & 3;  // {0,2,3,1}[(row>>2)&3]
+}
+
+template <int WP, int WC, int MODE>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c, long M, int Kg) {
+    constexpr int BP = WP * 64, BC = WC * 64;
+    constexpr int XR = BP * CHUNKS / 256;  // x rows per thread
+    constexpr int WR = BC * CHUNKS / 256;  // w rows per thread
+    constexpr int CS = BC + 8;             // epilogue row stride (elements)
+    constexpr int STAGE_BYTES = (BP + BC) * BK * 2;
+    constexpr int EPI_BYTES = BP * CS * 2;
+    constexpr int LDS_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave / WC, wc = wave % WC;
+
+    // XCD-aware remap: blocks that share an XCD (bid % 8) get a contiguous range of
+    // tiles, so the channel tiles of one pixel tile hit the same L2.  Bijective.
+    int lid;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        lid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+    }
+    const int tile_c = lid % tiles_c, tile_p = lid / tiles_c;
+    const long m0 = (long)tile_p * BP;
+    const int c0 = tile_c * BC;
+
+    const unsigned short* __restrict__ xg = (const unsigned short*)a.x;
+    const unsigned short* __restrict__ wg = (const unsigned short*)a.w;
+
+    // ---- per-thread gather state ----
+    const int chunk = tid & 3;
+    const int lrow = tid >> 2;  // 0..63
+    int hi0[XR], wi0[XR];
+    long nb[XR];
+    bool rvalid[XR];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        long m = m0 + lrow + i * 64;
+        rvalid[i] = m < M;
+        long mm = rvalid[i] ? m : 0;
+        int n = (int)(mm / HoWo);
+        int rem = (int)(mm - (long)n * HoWo);
+        int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        nb[i] = (long)n * a.H * a.W;
+        if (MODE == 0) { hi0[i] = ho * a.stride - a.pad; wi0[i] = wo * a.stride - a.pad; }
+        else           { hi0[i] = ho + a.pad;            wi0[i] = wo + a.pad; }
+    }
+    int kr = 0, ks = 0, kc = chunk * 8;  // (r, s, c) of this thread's chunk
+    while (kc >= a.C) { kc -= a.C; if (++ks == a.S) { ks = 0; ++kr; } }
+
+    uint4 xreg[XR], wreg[WR];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    auto load_tile = [&](int kt) {
+        const bool kok = kr < a.R;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            int hi, wi;
+            bool ok = rvalid[i] && kok;
+            if (MODE == 0) {
+                hi = hi0[i] + kr; wi = wi0[i] + ks;
+            } else {
+                int th = hi0[i] - kr, tw = wi0[i] - ks;
+                if (a.stride == 1) { hi = th; wi = tw; }
+                else {
+                    ok = ok && th >= 0 && tw >= 0;
+                    hi = th / a.stride; wi = tw / a.stride;
+                    ok = ok && (hi * a.stride == th) && (wi * a.stride == tw);
+                }
+            }
+            ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            xreg[i] = zero4;
+            if (ok) xreg[i] = *(const uint4*)(xg + ((nb[i] + (long)hi * a.W + wi) * a.C + kc));
+        }
+        const int k = kt * BK + chunk * 8;
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            int co = c0 + lrow + i * 64;
+            wreg[i] = zero4;
+            if (co < a.K && k < Kg) wreg[i] = *(const uint4*)(wg + ((long)co * Kg + k));
+        }
+        kc += BK;
+        while (kc >= a.C) { kc -= a.C; if (++ks == a.S) { ks = 0; ++kr; } }
+    };
+
+    const int wsw = chunk ^ swz4(lrow);  // (row>>2)&3 is the same for lrow + 64*i
+    auto store_tile = [&](int buf) {
+        unsigned char* xs = smem + buf * STAGE_BYTES;
+        unsigned char* ws = xs + BP * BK * 2;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) *(uint4*)(xs + ((lrow + i * 64) * CHUNKS + wsw) * 16) = xreg[i];
+#pragma unroll
+        for (int i = 0; i < WR; ++i) *(uint4*)(ws + ((lrow + i * 64) * CHUNKS + wsw) * 16) = wreg[i];
+    };
+
+    floatx4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (Kg + BK - 1) / BK;
+    const int frow = lane & 15;
+    const int fsw = (lane >> 4) ^ swz4(frow);
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const unsigned char* xs = smem + cur * STAGE_BYTES;
+        const unsigned char* ws = xs + BP * BK * 2;
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(ws + ((wc * 64 + i * 16 + frow) * CHUNKS + fsw) * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(xs + ((wp * 64 + j * 16 + frow) * CHUNKS + fsw) * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: bias/activation, stage the bf16 tile in LDS ----
+    unsigned short* cs = (unsigned short*)smem;
+    const int q4 = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int col = wc * 64 + i * 16 + q4;  // channel inside the block tile (4 consecutive)
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (c0 + col + r < a.K) b[r] = a.bias[c0 + col + r];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pix = wp * 64 + j * 16 + frow;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = acc[i][j][r] + b[r];
+                if (a.act == 1) t = fmaxf(t, 0.f);
+                else if (a.act == 2) t = gelu_tanh(t);
+                v[r] = t;
+            }
+            uint2 pk;
+            pk.x = pack_bf16x2(v[0], v[1]);
+            pk.y = pack_bf16x2(v[2], v[3]);
+            *(uint2*)(cs + pix * CS + col) = pk;
+        }
+    }
+    __syncthreads();
+
+    // ---- optional BatchNorm partial statistics: one (sum, sumsq) per channel per 64 rows ----
+    if (a.stats != nullptr) {
+        const int col = tid % BC, grp = tid / BC;  // BC * WP == 256
+        float s = 0.f, q = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) {
+            float v = bf16_to_float(cs[(grp * 64 + r) * CS + col]);
+            s += v; q += v * v;
+        }
+        const long srow = m0 / 64 + grp;
+        if (srow * 64 < M && c0 + col < a.K) {
+            a.stats[(srow * 2 + 0) * a.K + c0 + col] = s;
+            a.stats[(srow * 2 + 1) * a.K + c0 + col] = q;
+        }
+    }
+
+    // ---- coalesced write-out: 16 B per lane over full output rows ----
+    unsigned short* yg = (unsigned short*)a.y;
+    constexpr int CPR = BC / 8;        // chunks per row
+    constexpr int RPP = 256 / CPR;     // rows per pass
+    const int och = tid % CPR, orow = tid / CPR;
+#pragma unroll
+    for (int pss = 0; pss < BP / RPP; ++pss) {
+        const int row = pss * RPP + orow;
+        const long m = m0 + row;
+        const int co = c0 + och * 8;
+        if (m < M && co < a.K) {
+            uint4 v = *(const uint4*)(cs + row * CS + och * 8);
+            *(uint4*)(yg + m * a.K + co) = v;
+        }
+    }
+}
+
+template <int WP, int WC>
+void launch(const ConvArgs& a, hipStream_t st) {
+    const long M = (long)a.N * a.Ho * a.Wo;
+    const int Kg = a.R * a.S * a.C;
+    const int tiles_p = (int)((M + WP * 64 - 1) / (WP * 64));
+    const int tiles_c = (a.K + WC * 64 - 1) / (WC * 64);
+    dim3 grid(tiles_p * tiles_c), block(256);
+    if (a.mode == 0)
+        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 0>), grid, block, 0, st, a, tiles_c, M, Kg);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 1>), grid, block, 0, st, a, tiles_c, M, Kg);
+}
+
+}  // namespace
+
+int conv_stats_rows(long M) { return (int)((M + 63) / 64); }
+
+void conv_igemm(const ConvArgs& a, hipStream_t st) {
+    if (a.K <= 64) launch<4, 1>(a, st);
+    else launch<2, 2>(a, st);
+}
+
+// ------------------------------------------------------------------ filter transpose
+__global__ void transpose_filter_kernel(const unsigned short* __restrict__ w, unsigned short* __restrict__ wt,
+                                        int K, int RS, int C) {
+    // tile 32x32 over (k, c) for a fixed rs; LDS transpose
+    __shared__ unsigned short t[32][33];
+    const int rs = blockIdx.z;
+    const int k0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        int k = k0 + i, c = c0 + tx;
+        t[i][tx] = (k < K && c < C) ? w[((long)k * RS + rs) * C + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        int c = c0 + i, k = k0 + tx;
+        if (c < C && k < K) wt[((long)c * RS + rs) * K + k] = t[tx][i];
+    }
+}
+
+void transpose_filter(const void* w, void* wt, int K, int RS, int C, hipStream_t st) {
+    dim3 grid((C + 31) / 32, (K + 31) / 32, RS), block(256);
+    hipLaunchKernelGGL(transpose_filter_kernel, grid, block, 0, st, (const unsigned short*)w, (unsigned short*)wt, K, RS, C);
+}
+
+// ------------------------------------------------------------------ column sums (bias gradient)
+__global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __restrict__ x, float* __restrict__ out,
+                                                     long M, int K, long rows_per_block) {
+    // thread -> (8-channel chunk, row lane); K % 8 == 0
+    const int cpr = K / 8;
+    const int ch = threadIdx.x % cpr, rl = threadIdx.x / cpr, nrl = 256 / cpr;
+    __shared__ float red[256 * 8];
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (rl < nrl) {
+        const long r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+        for (long r = r0 + rl; r < r1; r += nrl) {
+            uint4 v = *(const uint4*)(x + r * K + ch * 8);
+            float f[8]; unpack8(v, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += f[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = (rl < nrl) ? s[j] : 0.f;
+    __syncthreads();
+    // first cpr*8 threads... each output channel summed over row lanes
+    for (int c = threadIdx.x; c < K; c += 256) {
+        float t = 0.f;
+        const int cch = c / 8, cj = c % 8;
+        for (int l = 0; l < nrl; ++l) t += red[(l * cpr + cch) * 8 + cj];
+        atomicAdd(out + c, t);
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const unsigned short* __restrict__ x, float* __restrict__ out,
+                                                          long M, int K, long rows_per_block) {
+    // K/8 > 256: thread -> chunk (grid.y tiles the channels), loop rows
+    const int ch = blockIdx.y * 256 + threadIdx.x;
+    if (ch * 8 >= K) return;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (long r = r0; r < r1; ++r) {
+        uint4 v = *(const uint4*)(x + r * K + ch * 8);
+        float f[8]; unpack8(v, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += f[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(out + ch * 8 + j, s[j]);
+}
+
+void colsum_bf16(const void* x, float* out, long M, int K, hipStream_t st) {
+    const int cpr = K / 8;
+    if (cpr <= 256) {
+        int blocks = (int)min((long)512, (M + 63) / 64);
+        if (blocks < 1) blocks = 1;
+        long rpb = (M + blocks - 1) / blocks;
+        hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, st, (const unsigned short*)x, out, M, K, rpb);
+    } else {
+        int by = (cpr + 255) / 256;
+        int blocks = (int)min((long)128, (M + 63) / 64);
+        if (blocks < 1) blocks = 1;
+        long rpb = (M + blocks - 1) / blocks;
+        hipLaunchKernelGGL(colsum_wide_kernel, dim3(blocks, by), dim3(256), 0, st, (const unsigned short*)x, out, M, K, rpb);
+    }
+}
+
+}  // namespace dpa

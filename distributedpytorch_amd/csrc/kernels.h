@@ -1,0 +1,136 @@
+// Host-side launcher API of the gfx950 kernels.  Plain C++ (no torch headers) so
+// the .hip translation units compile in seconds; bindings.cpp adapts tensors.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace dpa {
+
+// ---------------------------------------------------------------- conv / GEMM
+// Implicit-GEMM convolution on NHWC bf16 activations and KRSC bf16 filters.
+//   mode 0 (fprop):  y[n,ho,wo,k] = sum_{r,s,c} x[n, ho*stride-pad+r, wo*stride-pad+s, c] * w[k,r,s,c]
+//   mode 1 (dgrad):  y[n,h,w,k]   = sum_{r,s,c} x[n, (h+pad-r)/stride, (w+pad-s)/stride, c] * w[k,r,s,c]
+//                    (taps whose quotient is not integral / out of range contribute 0;
+//                     x is dy, w is the filter with its K and C axes swapped, k runs
+//                     over the forward conv's input channels)
+// A Linear layer is the R=S=1, H=W=1 case (N = rows).
+struct ConvArgs {
+    const void* x;      // bf16 [N, H, W, C]
+    const void* w;      // bf16 [K, R, S, C]
+    void* y;            // bf16 [N, Ho, Wo, K]
+    const float* bias;  // fp32 [K] or nullptr
+    float* stats;       // fp32 [ceil(M/64)][2][K] partial (sum, sumsq) per 64 output rows, or nullptr
+    int N, H, W, C, K, R, S, Ho, Wo;
+    int stride, pad;
+    int mode;           // 0 fprop, 1 dgrad
+    int act;            // 0 none, 1 relu, 2 gelu(tanh)
+};
+void conv_igemm(const ConvArgs& a, hipStream_t st);
+int conv_stats_rows(long M);  // rows of the stats partial buffer for M output pixels
+
+// wgrad: dw[k,r,s,c] += sum_{n,ho,wo} dy[n,ho,wo,k] * x[n, ho*stride-pad+r, wo*stride-pad+s, c]
+// dw is fp32 and is accumulated into with float atomics (split over the pixel axis).
+struct WgradArgs {
+    const void* x;    // bf16 [N, H, W, C]
+    const void* dy;   // bf16 [N, Ho, Wo, K]
+    float* dw;        // fp32 [K, R, S, C]
+    int N, H, W, C, K, R, S, Ho, Wo;
+    int stride, pad;
+};
+void conv_wgrad(const WgradArgs& a, hipStream_t st);
+
+// [K, RS, C] bf16 -> [C, RS, K] bf16 (filter for dgrad)
+void transpose_filter(const void* w, void* wt, int K, int RS, int C, hipStream_t st);
+// column sums of a bf16 [M, K] matrix into fp32 [K] (bias gradient), accumulates.
+void colsum_bf16(const void* x, float* out, long M, int K, hipStream_t st);
+
+// ---------------------------------------------------------------- batch norm (NHWC, rows = N*H*W)
+// partial (sum,sumsq) per block of rows -> stats[rows][2][C]
+int bn_stats_rows(long P);
+void bn_stats(const void* x, float* stats, long P, int C, hipStream_t st);
+// out[o][:] = sum of in rows [o*chunk, (o+1)*chunk); cols floats per row (fold a tall partial buffer)
+void fold_rows(const float* in, int rows, int cols, int chunk, float* out, hipStream_t st);
+// reduce partials, produce per-channel scale/shift + saved mean/invstd, update running stats
+void bn_finalize(const float* stats, int rows, long P, int C, const float* gamma, const float* beta,
+                 float* running_mean, float* running_var, float momentum, float eps,
+                 float* mean, float* invstd, float* scale, float* shift, hipStream_t st);
+// y = act(x*scale[c] + shift[c] (+ residual))
+void bn_apply(const void* x, const void* residual, void* y, const float* scale, const float* shift,
+              long P, int C, int relu, hipStream_t st);
+// backward pass 1: g = dy * (relu ? y>0 : 1); partial sums of g and g*xhat per block of rows
+void bn_bwd_stats(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                  float* stats, long P, int C, int relu, hipStream_t st);
+// reduce partials -> dgamma, dbeta (accumulate=0: overwrite) and coefficients A,B,C0 with dx = A*g + B*x + C0
+void bn_bwd_finalize(const float* stats, int rows, long P, int C, const float* gamma, const float* mean,
+                     const float* invstd, float* dgamma, float* dbeta, float* coefA, float* coefB, float* coefC,
+                     hipStream_t st);
+// backward pass 2: dx = A*g + B*x + C0 ; optionally dres = g
+void bn_bwd_apply(const void* dy, const void* y, const void* x, const float* coefA, const float* coefB,
+                  const float* coefC, void* dx, void* dres, long P, int C, int relu, hipStream_t st);
+
+// ---------------------------------------------------------------- pooling / layout
+void maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int Ho, int Wo, hipStream_t st);
+void maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C, int Ho, int Wo, hipStream_t st);
+void avgpool_fwd(const void* x, void* y, int N, int HW, int C, hipStream_t st);
+void avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, hipStream_t st);
+// NCHW (fp32 or bf16) -> NHWC bf16 with channel padding to Cpad
+void nchw_to_nhwc_pad(const void* x, int x_is_bf16, void* y, int N, int C, int H, int W, int Cpad, hipStream_t st);
+// elementwise on bf16: y = a + b ; relu variants
+void add_bf16(const void* a, const void* b, void* y, long n, hipStream_t st);
+void add_relu_fwd(const void* a, const void* b, void* y, long n, hipStream_t st);
+void relu_bwd(const void* dy, const void* y, void* dx, long n, hipStream_t st);
+void gelu_fwd(const void* x, void* y, long n, hipStream_t st);
+void gelu_bwd(const void* dy, const void* x, void* dx, long n, hipStream_t st);
+
+// ---------------------------------------------------------------- loss
+// logits [B, V] (bf16 or fp32, row stride ld); loss_sum += sum_b (lse_b - logit_b[target_b]) * scale
+void softmax_ce_fwd(const void* logits, int is_bf16, const int64_t* targets, float* lse, float* loss_sum,
+                    long B, int V, long ld, float scale, int64_t ignore_index, hipStream_t st);
+// dlogits = (softmax - onehot) * (*gscale_ptr) * scale ; may alias logits
+void softmax_ce_bwd(const void* logits, int is_bf16, const int64_t* targets, const float* lse, const float* gscale_ptr,
+                    void* dlogits, long B, int V, long ld, float scale, int64_t ignore_index, hipStream_t st);
+
+// ---------------------------------------------------------------- optimizer
+// fused SGD-momentum over a flat buffer:
+//   g' = g*grad_scale + wd*p ; m = mu*m + g' ; p -= lr*m ; p_lp = bf16(p) ; g = 0 (if zero_grad)
+void sgd_momentum(float* p, float* g, float* m, void* p_lp, long n, float lr, float mu, float wd,
+                  float grad_scale, int zero_grad, int nesterov, hipStream_t st);
+void adamw(float* p, float* g, float* m, float* v, void* p_lp, long n, float lr, float b1, float b2, float eps,
+           float wd, float grad_scale, float bc1, float bc2, int zero_grad, hipStream_t st);
+void cast_f32_to_bf16(const float* x, void* y, long n, hipStream_t st);
+void cast_bf16_to_f32(const void* x, float* y, long n, hipStream_t st);
+void scale_f32(float* x, long n, float s, hipStream_t st);
+
+// ---------------------------------------------------------------- transformer pieces
+void layernorm_fwd(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd,
+                   long rows, int C, float eps, hipStream_t st);
+void layernorm_bwd(const void* dy, const void* x, const float* g, const float* mean, const float* rstd,
+                   void* dx, float* dg_partial, float* db_partial, int partial_rows, long rows, int C, hipStream_t st);
+int layernorm_partial_rows(long rows);
+void reduce_partials(const float* partial, int rows, int C, float* out, int accumulate, hipStream_t st);
+void embedding_fwd(const int64_t* tok, const void* wte, const void* wpe, void* y, long B, int T, int C, hipStream_t st);
+void embedding_bwd(const int64_t* tok, const void* dy, float* dwte, float* dwpe, long B, int T, int C, hipStream_t st);
+// causal flash attention, qkv packed [B, T, 3, H, D] bf16, D = 64
+void attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int D, hipStream_t st);
+void attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,
+                   int B, int T, int H, int D, hipStream_t st);
+
+// ---------------------------------------------------------------- small MNIST CNN (fp32, NCHW; reference model)
+// y = relu(maxpool2(conv5x5(x) + b)) fused ; idx = argmax position in the 2x2 window
+void conv5_pool_relu_fwd(const float* x, const float* w, const float* b, float* y, uint8_t* idx,
+                         int N, int Cin, int H, int W, int Cout, const float* drop_mask, hipStream_t st);
+void conv5_pool_relu_bwd(const float* x, const float* w, const float* dy, const float* y, const uint8_t* idx,
+                         float* dx, float* dw, float* db, int N, int Cin, int H, int W, int Cout,
+                         const float* drop_mask, hipStream_t st);
+// y = act(x @ w^T + b) fp32 small GEMM (rows x in -> rows x out)
+void linear_f32_fwd(const float* x, const float* w, const float* b, float* y, int rows, int in, int out, int relu, hipStream_t st);
+void linear_f32_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* db,
+                    int rows, int in, int out, int relu, hipStream_t st);
+void log_softmax_fwd(const float* x, float* y, int rows, int V, hipStream_t st);
+void log_softmax_bwd(const float* dy, const float* y, float* dx, int rows, int V, hipStream_t st);
+void nll_fwd(const float* logp, const int64_t* t, float* loss, int rows, int V, hipStream_t st);
+void nll_bwd(const float* g, const int64_t* t, float* dlogp, int rows, int V, hipStream_t st);
+void dropout_mask(float* mask, long n, float p, uint64_t seed, uint64_t offset, hipStream_t st);
+void mul_f32(const float* a, const float* b, float* y, long n, hipStream_t st);
+
+}  // namespace dpa

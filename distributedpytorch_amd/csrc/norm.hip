@@ -1,0 +1,279 @@
+// BatchNorm (training mode) on NHWC bf16 for gfx950 - memory-bound kernels.
+//
+// All kernels view the tensor as [P = N*H*W rows][C channels], C % 8 == 0, and move
+// 16 B (8 bf16) per lane so a wave covers whole 128-byte lines.  Reductions over
+// rows are two-stage: every block writes one partial row (plain stores, no
+// atomics - 1000s of blocks adding into the same few hundred floats would run at
+// the contended-atomic rate), and a tiny finalize kernel folds the partials and
+// produces per-channel affine coefficients, so the big passes are pure streaming
+// FMA.  The forward statistics are normally produced by the convolution epilogue
+// (conv_igemm.hip), which makes bn_stats unnecessary on the hot path.
+#include "common.h"
+#include "kernels.h"
+
+namespace dpa {
+namespace {
+
+// rows folded into one partial by bn_stats / bn_bwd_stats: enough blocks to fill the
+// chip (>= ~2048 when the tensor allows it), at most 256 rows per block
+inline int rows_per_block(long P) {
+    long r = (P + 2047) / 2048;
+    r = (r + 15) / 16 * 16;
+    if (r < 16) r = 16;
+    if (r > 256) r = 256;
+    return (int)r;
+}
+
+// generic two-quantity row reduction.  F(row, chunk) -> 8 x (a, b) contributions.
+template <class F>
+__device__ __forceinline__ void reduce_rows(F f, float* __restrict__ stats, long P, int C, int rpb) {
+    const int cpr = C / 8;                       // chunks per row
+    const int ch = threadIdx.x % cpr, rl = threadIdx.x / cpr, nrl = 256 / cpr;
+    __shared__ float red[2][256][9];
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    const long r0 = (long)blockIdx.x * rpb;
+    long r1 = r0 + rpb; if (r1 > P) r1 = P;
+    if (rl < nrl)
+        for (long r = r0 + rl; r < r1; r += nrl) f(r, ch, s, q);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[0][threadIdx.x][j] = s[j]; red[1][threadIdx.x][j] = q[j]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float ts = 0.f, tq = 0.f;
+        const int cch = c >> 3, cj = c & 7;
+        for (int l = 0; l < nrl; ++l) { ts += red[0][l * cpr + cch][cj]; tq += red[1][l * cpr + cch][cj]; }
+        stats[((long)blockIdx.x * 2 + 0) * C + c] = ts;
+        stats[((long)blockIdx.x * 2 + 1) * C + c] = tq;
+    }
+}
+
+// C > 2048 (cpr > 256) is not used by BatchNorm layers here; wide C is tiled by grid.y
+__global__ __launch_bounds__(256) void bn_stats_kernel(const unsigned short* __restrict__ x, float* __restrict__ stats,
+                                                       long P, int C, int rpb) {
+    reduce_rows([&](long r, int ch, float (&s)[8], float (&q)[8]) {
+        uint4 v = *(const uint4*)(x + r * C + ch * 8);
+        float f[8]; unpack8(v, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+    }, stats, P, C, rpb);
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int rows, long P, int C,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* running_mean, float* running_var, float momentum, float eps,
+                                                          float* __restrict__ mean, float* __restrict__ invstd,
+                                                          float* __restrict__ scale, float* __restrict__ shift) {
+    // block = 64 channels x 4 row lanes
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    __shared__ double red[2][4][64];
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int r = rl; r < rows; r += 4) { s += stats[((long)r * 2) * C + c]; q += stats[((long)r * 2 + 1) * C + c]; }
+    red[0][rl][threadIdx.x & 63] = s; red[1][rl][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const int l = threadIdx.x & 63;
+        s = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+        q = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+        const double m = s / (double)P;
+        double var = q / (double)P - m * m;
+        if (var < 0.0) var = 0.0;
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        mean[c] = (float)m; invstd[c] = is;
+        const float g = gamma[c];
+        scale[c] = g * is;
+        shift[c] = beta[c] - (float)m * g * is;
+        if (running_mean != nullptr) {
+            const double unbiased = P > 1 ? var * (double)P / (double)(P - 1) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ res,
+                                                       unsigned short* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, long nchunks, int cpr) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % cpr);
+        uint4 v = *(const uint4*)(x + i * 8);
+        float f[8]; unpack8(v, f);
+        const float4 s0 = *(const float4*)(scale + ch * 8), s1 = *(const float4*)(scale + ch * 8 + 4);
+        const float4 b0 = *(const float4*)(shift + ch * 8), b1 = *(const float4*)(shift + ch * 8 + 4);
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (RES) { uint4 rv = *(const uint4*)(res + i * 8); unpack8(rv, r); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = f[j] * sc[j] + sh[j] + r[j];
+            if (RELU) t = fmaxf(t, 0.f);
+            f[j] = t;
+        }
+        *(uint4*)(y + i * 8) = pack8(f);
+    }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ y,
+                                                           const unsigned short* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, float* __restrict__ stats,
+                                                           long P, int C, int rpb) {
+    reduce_rows([&](long r, int ch, float (&s)[8], float (&q)[8]) {
+        uint4 dv = *(const uint4*)(dy + r * C + ch * 8);
+        uint4 xv = *(const uint4*)(x + r * C + ch * 8);
+        float g[8], xf[8]; unpack8(dv, g); unpack8(xv, xf);
+        if (RELU) {
+            uint4 yv = *(const uint4*)(y + r * C + ch * 8);
+            float yf[8]; unpack8(yv, yf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = yf[j] > 0.f ? g[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = (xf[j] - mean[ch * 8 + j]) * invstd[ch * 8 + j];
+            s[j] += g[j]; q[j] += g[j] * xh;
+        }
+    }, stats, P, C, rpb);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ stats, int rows, long P, int C,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ cA,
+                                                              float* __restrict__ cB, float* __restrict__ cC) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    __shared__ double red[2][4][64];
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int r = rl; r < rows; r += 4) { s += stats[((long)r * 2) * C + c]; q += stats[((long)r * 2 + 1) * C + c]; }
+    red[0][rl][threadIdx.x & 63] = s; red[1][rl][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const int l = threadIdx.x & 63;
+        s = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];   // sum g       = dbeta
+        q = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];   // sum g*xhat  = dgamma
+        dbeta[c] = (float)s; dgamma[c] = (float)q;
+        const double g = gamma[c], is = invstd[c], m = mean[c], invP = 1.0 / (double)P;
+        // dx = g*is*(gy - s/P - xhat*q/P),  xhat = (x-m)*is
+        cA[c] = (float)(g * is);
+        cB[c] = (float)(-g * is * is * q * invP);
+        cC[c] = (float)(g * is * (m * is * q * invP - s * invP));
+    }
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ y,
+                                                           const unsigned short* __restrict__ x, const float* __restrict__ cA,
+                                                           const float* __restrict__ cB, const float* __restrict__ cC,
+                                                           unsigned short* __restrict__ dx, unsigned short* __restrict__ dres,
+                                                           long nchunks, int cpr) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % cpr);
+        float g[8], xf[8];
+        { uint4 v = *(const uint4*)(dy + i * 8); unpack8(v, g); }
+        { uint4 v = *(const uint4*)(x + i * 8); unpack8(v, xf); }
+        if (RELU) {
+            uint4 yv = *(const uint4*)(y + i * 8);
+            float yf[8]; unpack8(yv, yf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = yf[j] > 0.f ? g[j] : 0.f;
+        }
+        if (RES) *(uint4*)(dres + i * 8) = pack8(g);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = cA[ch * 8 + j] * g[j] + cB[ch * 8 + j] * xf[j] + cC[ch * 8 + j];
+        *(uint4*)(dx + i * 8) = pack8(o);
+    }
+}
+
+// fold partial rows: out[o][col] = sum of in rows [o*chunk, (o+1)*chunk)
+__global__ __launch_bounds__(256) void fold_rows_kernel(const float* __restrict__ in, int rows, int cols, int chunk,
+                                                        float* __restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= cols) return;
+    const int r0 = blockIdx.y * chunk;
+    int r1 = r0 + chunk; if (r1 > rows) r1 = rows;
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += in[(long)r * cols + col];
+    out[(long)blockIdx.y * cols + col] = s;
+}
+
+inline int stream_grid(long nchunks) {
+    long b = (nchunks + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+void fold_rows(const float* in, int rows, int cols, int chunk, float* out, hipStream_t st) {
+    dim3 g((cols + 255) / 256, (rows + chunk - 1) / chunk), b(256);
+    hipLaunchKernelGGL(fold_rows_kernel, g, b, 0, st, in, rows, cols, chunk, out);
+}
+
+int bn_stats_rows(long P) { const int r = rows_per_block(P); return (int)((P + r - 1) / r); }
+
+void bn_stats(const void* x, float* stats, long P, int C, hipStream_t st) {
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(bn_stats_rows(P)), dim3(256), 0, st, (const unsigned short*)x, stats, P, C, rows_per_block(P));
+}
+
+void bn_finalize(const float* stats, int rows, long P, int C, const float* gamma, const float* beta,
+                 float* running_mean, float* running_var, float momentum, float eps,
+                 float* mean, float* invstd, float* scale, float* shift, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, stats, rows, P, C, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+}
+
+void bn_apply(const void* x, const void* residual, void* y, const float* scale, const float* shift,
+              long P, int C, int relu, hipStream_t st) {
+    const long nchunks = P * C / 8;
+    const int cpr = C / 8;
+    dim3 g(stream_grid(nchunks)), b(256);
+    auto X = (const unsigned short*)x; auto R = (const unsigned short*)residual; auto Y = (unsigned short*)y;
+    if (relu) {
+        if (R) hipLaunchKernelGGL((bn_apply_kernel<true, true>), g, b, 0, st, X, R, Y, scale, shift, nchunks, cpr);
+        else   hipLaunchKernelGGL((bn_apply_kernel<true, false>), g, b, 0, st, X, R, Y, scale, shift, nchunks, cpr);
+    } else {
+        if (R) hipLaunchKernelGGL((bn_apply_kernel<false, true>), g, b, 0, st, X, R, Y, scale, shift, nchunks, cpr);
+        else   hipLaunchKernelGGL((bn_apply_kernel<false, false>), g, b, 0, st, X, R, Y, scale, shift, nchunks, cpr);
+    }
+}
+
+void bn_bwd_stats(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                  float* stats, long P, int C, int relu, hipStream_t st) {
+    dim3 g(bn_stats_rows(P)), b(256);
+    if (relu) hipLaunchKernelGGL((bn_bwd_stats_kernel<true>), g, b, 0, st, (const unsigned short*)dy, (const unsigned short*)y,
+                                 (const unsigned short*)x, mean, invstd, stats, P, C, rows_per_block(P));
+    else      hipLaunchKernelGGL((bn_bwd_stats_kernel<false>), g, b, 0, st, (const unsigned short*)dy, (const unsigned short*)y,
+                                 (const unsigned short*)x, mean, invstd, stats, P, C, rows_per_block(P));
+}
+
+void bn_bwd_finalize(const float* stats, int rows, long P, int C, const float* gamma, const float* mean,
+                     const float* invstd, float* dgamma, float* dbeta, float* coefA, float* coefB, float* coefC,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, stats, rows, P, C, gamma, mean, invstd,
+                       dgamma, dbeta, coefA, coefB, coefC);
+}
+
+void bn_bwd_apply(const void* dy, const void* y, const void* x, const float* coefA, const float* coefB,
+                  const float* coefC, void* dx, void* dres, long P, int C, int relu, hipStream_t st) {
+    const long nchunks = P * C / 8;
+    const int cpr = C / 8;
+    dim3 g(stream_grid(nchunks)), b(256);
+    auto DY = (const unsigned short*)dy; auto Y = (const unsigned short*)y; auto X = (const unsigned short*)x;
+    auto DX = (unsigned short*)dx; auto DR = (unsigned short*)dres;
+    if (relu) {
+        if (DR) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), g, b, 0, st, DY, Y, X, coefA, coefB, coefC, DX, DR, nchunks, cpr);
+        else    hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), g, b, 0, st, DY, Y, X, coefA, coefB, coefC, DX, DR, nchunks, cpr);
+    } else {
+        if (DR) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), g, b, 0, st, DY, Y, X, coefA, coefB, coefC, DX, DR, nchunks, cpr);
+        else    hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), g, b, 0, st, DY, Y, X, coefA, coefB, coefC, DX, DR, nchunks, cpr);
+    }
+}
+
+}  // namespace dpa

@@ -1,0 +1,187 @@
+"""Dataset partitioning and synthetic datasets.
+
+``Partition`` / ``DataPartitioner`` keep the reference's semantics
+(multinode-DP/multinodeDP.py:42-75): a ``random.Random`` seeded with 1234 shuffles
+``range(len(data))`` and consecutive chunks of ``int(frac * len)`` indices are cut
+per entry of ``sizes``.  Because every rank uses the same seed they all compute the
+same permutation, so the shards are disjoint and consistent with no communication.
+
+torchvision is not available on the target image and there is no network, so the
+datasets are synthetic tensors of the named shapes (MNIST 1x28x28, ImageNet
+3x224x224, GPT-2 token streams), generated deterministically from a seed - on the
+device when one is given, so the input pipeline can never stall the GPU.
+"""
+from __future__ import annotations
+
+from math import ceil
+from random import Random
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+
+class Partition:
+    """Dataset-like view of a subset of ``data`` (reference DP.py:42-55)."""
+
+    def __init__(self, data, index: Sequence[int]):
+        self.data = data
+        self.index = index
+
+    def __len__(self) -> int:
+        return len(self.index)
+
+    def __getitem__(self, i):
+        return self.data[self.index[i]]
+
+
+class DataPartitioner:
+    """Seeded, communication-free partitioning (reference DP.py:57-75)."""
+
+    def __init__(self, data, sizes: Sequence[float] = (0.7, 0.2, 0.1), seed: int = 1234):
+        self.data = data
+        self.partitions: List[List[int]] = []
+        rng = Random()
+        rng.seed(seed)
+        n = len(data)
+        order = list(range(n))
+        rng.shuffle(order)
+        start = 0
+        for frac in sizes:
+            part_len = int(frac * n)
+            self.partitions.append(order[start:start + part_len])
+            start += part_len
+
+    def use(self, partition: int) -> Partition:
+        return Partition(self.data, self.partitions[partition])
+
+
+class SyntheticImageDataset:
+    """Deterministic fake images + labels, materialised lazily per index block.
+
+    Samples are a pure function of ``(seed, index)`` so any rank can produce any
+    sample; class-dependent means make the task learnable (loss must go down in the
+    end-to-end tests).
+    """
+
+    def __init__(self, n: int = 60000, shape: Tuple[int, int, int] = (1, 28, 28), classes: int = 10,
+                 seed: int = 1234, device: Optional[torch.device] = None):
+        self.n, self.shape, self.classes, self.seed = n, tuple(shape), classes, seed
+        self.device = device or torch.device("cpu")
+        g = torch.Generator().manual_seed(seed)
+        self.labels = torch.randint(0, classes, (n,), generator=g)
+        # one low-rank "prototype" per class
+        self.proto = torch.randn(classes, *self.shape, generator=g) * 0.5
+
+    def __len__(self) -> int:
+        return self.n
+
+    def __getitem__(self, i: int):
+        y = int(self.labels[i])
+        g = torch.Generator().manual_seed(self.seed * 1000003 + int(i))
+        x = self.proto[y] + 0.3 * torch.randn(self.shape, generator=g)
+        return x, y
+
+    def batch(self, indices: Sequence[int]):
+        idx = torch.as_tensor(list(indices), dtype=torch.long)
+        y = self.labels[idx]
+        g = torch.Generator().manual_seed(self.seed * 1000003 + int(idx[0]) if len(idx) else self.seed)
+        x = self.proto[y] + 0.3 * torch.randn((len(idx),) + self.shape, generator=g)
+        return x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
+
+
+class SyntheticTokenDataset:
+    """Token sequences for GPT-2 shaped workloads: ``(tokens[S], targets[S])``."""
+
+    def __init__(self, n: int = 4096, seq_len: int = 1024, vocab: int = 50257, seed: int = 1234):
+        self.n, self.seq_len, self.vocab, self.seed = n, seq_len, vocab, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 7919 + int(i))
+        t = torch.randint(0, self.vocab, (self.seq_len + 1,), generator=g)
+        return t[:-1], t[1:]
+
+    def batch(self, indices, device=None):
+        xs, ys = zip(*(self[i] for i in indices))
+        x, y = torch.stack(xs), torch.stack(ys)
+        if device is not None:
+            x, y = x.to(device), y.to(device)
+        return x, y
+
+
+class BatchLoader:
+    """Minimal loader over a ``Partition``: optional per-epoch seeded shuffle,
+    ragged last batch kept (the reference's DataLoader has no ``drop_last``,
+    DP.py:113-114, so the last batch is short: 12 at world 8)."""
+
+    def __init__(self, partition, batch_size: int, shuffle: bool = True, seed: int = 0, drop_last: bool = False,
+                 device: Optional[torch.device] = None):
+        if batch_size < 1:
+            raise ValueError("batch_size must be >= 1 (global batch smaller than world size?)")
+        self.partition, self.batch_size, self.shuffle = partition, int(batch_size), shuffle
+        self.seed, self.drop_last, self.device = seed, drop_last, device
+        self.epoch = 0
+        self.dataset = partition  # attribute name used by the reference (DP.py:145)
+
+    def __len__(self) -> int:
+        n = len(self.partition)
+        return n // self.batch_size if self.drop_last else ceil(n / self.batch_size)
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+
+    def __iter__(self):
+        n = len(self.partition)
+        order = list(range(n))
+        if self.shuffle:
+            Random(self.seed * 9973 + self.epoch).shuffle(order)
+        base = self.partition.data if isinstance(self.partition, Partition) else self.partition
+        index = self.partition.index if isinstance(self.partition, Partition) else None
+        for lo in range(0, n, self.batch_size):
+            chunk = order[lo:lo + self.batch_size]
+            if self.drop_last and len(chunk) < self.batch_size:
+                return
+            ids = [index[i] for i in chunk] if index is not None else chunk
+            if hasattr(base, "batch"):
+                x, y = base.batch(ids)
+            else:
+                xs, ys = zip(*(base[i] for i in ids))
+                x = torch.stack([torch.as_tensor(v) for v in xs])
+                y = torch.as_tensor(ys)
+            if self.device is not None:
+                x, y = x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
+            yield x, y
+        self.epoch += 1
+
+
+def partition_dataset(dataset, rank: int, world_size: int, global_batch: int = 128, seed: int = 1234,
+                      device: Optional[torch.device] = None, shuffle: bool = True):
+    """Reference ``partition_dataset`` (DP.py:98-116): equal shards, global batch
+    fixed, per-rank batch = ``int(global_batch / world_size)``.  Returns
+    ``(loader, bsz)`` with ``bsz`` the *float* per-rank batch, as the reference does
+    (it is used for ``num_batches = ceil(len(partition) / bsz)``, DP.py:145)."""
+    bsz = global_batch / float(world_size)
+    sizes = [1.0 / world_size for _ in range(world_size)]
+    part = DataPartitioner(dataset, sizes, seed=seed).use(rank)
+    loader = BatchLoader(part, int(bsz), shuffle=shuffle, seed=seed + rank, device=device)
+    return loader, bsz
+
+
+def synthetic_batch(kind: str, batch: int, device, dtype=torch.float32, seed: int = 0, seq_len: int = 1024,
+                    vocab: int = 50257, classes: int = 1000):
+    """One on-device synthetic batch of a named shape, for benchmarks."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    if kind == "mnist":
+        x = torch.randn(batch, 1, 28, 28, generator=g, device=device, dtype=torch.float32).to(dtype)
+        y = torch.randint(0, 10, (batch,), generator=g, device=device)
+    elif kind == "imagenet":
+        x = torch.randn(batch, 3, 224, 224, generator=g, device=device, dtype=torch.float32).to(dtype)
+        y = torch.randint(0, classes, (batch,), generator=g, device=device)
+    elif kind == "tokens":
+        t = torch.randint(0, vocab, (batch, seq_len + 1), generator=g, device=device)
+        x, y = t[:, :-1].contiguous(), t[:, 1:].contiguous()
+    else:
+        raise ValueError(kind)
+    return x, y
