@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Headline benchmark: ResNet-50 data-parallel training throughput (images/sec, whole job).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by the driver as
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`` (one rank
+per GPU over RCCL; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the env).
+Every rank runs the FULL training step on its own synthetic 3x224x224 batch
+(weak scaling): layout conversion, forward, loss, backward, bucketed all-reduce
+overlapped with backward, fused SGD-momentum update (bf16 compute, fp32 master
+weights / gradients).  Rank 0 prints ONE JSON line.
+
+Other workloads: ``--model resnet152|gpt2|mnist``; ``--pipeline S`` runs an S-stage
+micro-batched pipeline (ranks = stages x replicas) and reports the same metric.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--model", default="resnet50", choices=["resnet50", "resnet152", "gpt2", "mnist", "tiny_resnet"])
+    p.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 256 resnet50, 8 gpt2, 128/N mnist)")
+    p.add_argument("--seq-len", type=int, default=1024)
+    p.add_argument("--bucket-mb", type=float, default=32.0)
+    p.add_argument("--first-bucket-mb", type=float, default=4.0)
+    p.add_argument("--pipeline", type=int, default=0, help="number of pipeline stages (0 = pure data parallel)")
+    p.add_argument("--micro-batches", type=int, default=8)
+    p.add_argument("--schedule", default="1f1b")
+    p.add_argument("--no-sink", action="store_true")
+    p.add_argument("--backend", default="auto")
+    return p.parse_args()
+
+
+def load_baseline(model: str, n: int):
+    """Stock PyTorch-ROCm numbers measured by scripts/baseline_torch.py on MI355X.
+    The reference itself publishes none.  For N > 1 the comparison line is N x the measured
+    1-GPU stock number (i.e. stock PyTorch given perfect scaling)."""
+    path = os.path.join(ROOT, "BASELINE_MEASURED.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            data = json.load(f)
+        entry = data.get(model, {})
+        if str(n) in entry:
+            return float(entry[str(n)])
+        if "1" in entry:
+            return float(entry["1"]) * n
+    except Exception:  # noqa: BLE001
+        return None
+    return None
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (MI355X); none visible")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from distributedpytorch_amd import comm as dcomm
+    from distributedpytorch_amd.optim import FusedSGD
+    from distributedpytorch_amd.parallel.dp import DataParallel
+    from distributedpytorch_amd.data import synthetic_batch
+
+    if world > 1:
+        communicator = dcomm.init_process_group(args.backend, init_method=None, device=device)
+    else:
+        communicator = dcomm.Communicator(device=device)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    torch.manual_seed(1234)
+    unit = "images/sec"
+    if args.pipeline and args.pipeline > 1:
+        from distributedpytorch_amd.parallel.pp import run_pipeline_bench
+        result = run_pipeline_bench(args, communicator, device)
+    else:
+        if args.model in ("resnet50", "resnet152", "tiny_resnet"):
+            from distributedpytorch_amd.models import resnet
+            batch = args.batch or 256
+            if args.model == "tiny_resnet":
+                model = resnet.tiny_resnet(); hw, classes = 64, 16
+            else:
+                model = getattr(resnet, args.model)(); hw, classes = 224, 1000
+            model = model.to(device).train()
+            g = torch.Generator(device=device).manual_seed(1234 + rank)
+            x = torch.randn(batch, 3, hw, hw, generator=g, device=device)
+            y = torch.randint(0, classes, (batch,), generator=g, device=device)
+            lr, momentum, wd, use_lp = 0.1, 0.9, 1e-4, True
+            loss_fn = lambda: model.loss(x, y)  # noqa: E731
+            items = batch
+            cfg = {"model": args.model, "global_batch": batch * world, "image": f"3x{hw}x{hw}"}
+        elif args.model == "gpt2":
+            from distributedpytorch_amd.models import gpt2
+            batch = args.batch or 8
+            model = gpt2.gpt2_small().to(device).train()
+            x, y = synthetic_batch("tokens", batch, device, seed=1234 + rank, seq_len=args.seq_len)
+            lr, momentum, wd, use_lp = 0.01, 0.9, 0.0, True
+            loss_fn = lambda: model.loss(x, y)  # noqa: E731
+            items = batch * args.seq_len
+            unit = "tokens/sec"
+            cfg = {"model": "gpt2-small-124M", "global_batch": batch * world, "seq_len": args.seq_len}
+        else:  # mnist: the reference's own DP config (global batch 128, SGD lr .01 momentum .5)
+            from distributedpytorch_amd.models import mnist
+            batch = args.batch or max(1, 128 // world)
+            model = mnist.Net().to(device).train()
+            x, y = synthetic_batch("mnist", batch, device, seed=1234 + rank)
+            lr, momentum, wd, use_lp = 0.01, 0.5, 0.0, False
+            loss_fn = lambda: mnist.nll_loss(model(x), y)  # noqa: E731
+            items = batch
+            cfg = {"model": "mnist_cnn", "global_batch": batch * world, "image": "1x28x28"}
+
+        dp = DataParallel(model, communicator, bucket_mb=args.bucket_mb, first_bucket_mb=args.first_bucket_mb,
+                          use_sink=not args.no_sink, use_lp=use_lp)
+        opt = FusedSGD(dp.flat, lr=lr, momentum=momentum, weight_decay=wd)
+        opt.grad_scale = dp.grad_scale
+
+        def step():
+            loss = loss_fn()
+            loss.backward()
+            dp.finish()
+            opt.step()
+            return loss
+
+        for _ in range(args.warmup):
+            step()
+        communicator.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        communicator.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        elapsed = communicator.all_reduce_scalar(elapsed, "max")
+        result = {"elapsed": elapsed, "items_per_rank_step": items, "loss": float(loss.detach().float().cpu()),
+                  "config": dict(cfg, parallelism=f"dp{world}", per_gpu_batch=batch,
+                                 buckets=len(dp.buckets), optimizer=f"fused SGD momentum {momentum}")}
+
+    if rank == 0:
+        elapsed = result["elapsed"]
+        value = result["items_per_rank_step"] * result.get("dp_world", world) * args.steps / elapsed
+        base = load_baseline(args.model, world)
+        metric = "images/sec (whole node) ResNet-50 DP" if args.model == "resnet50" and not args.pipeline else \
+            f"{unit} (whole job) {args.model}"
+        out = {
+            "metric": metric, "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": (round(value / base, 4) if base else None), "dtype": "bf16" if args.model != "mnist" else "fp32",
+            "data": "synthetic (random-init weights, on-device random inputs of the named shape)",
+            "final_loss": result["loss"], "config": result["config"],
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        communicator.barrier()
+        dcomm.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

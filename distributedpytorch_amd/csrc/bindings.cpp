@@ -1,0 +1,498 @@
+// Python bindings: adapt torch tensors to the raw-pointer launcher API of kernels.h.
+// Every entry point validates dtype / shape / contiguity / alignment on the host
+// BEFORE launching (an out-of-bounds kernel access can reset the whole GPU), and
+// launches on PyTorch's current HIP stream so ordering with autograd is implicit.
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPGuard.h>
+
+#include "kernels.h"
+
+namespace {
+
+using torch::Tensor;
+
+inline hipStream_t cur_stream() { return c10::hip::getCurrentHIPStream().stream(); }
+
+#define CHECK_DEV(t) TORCH_CHECK((t).is_cuda(), #t " must be a GPU tensor")
+#define CHECK_CONTIG(t) TORCH_CHECK((t).is_contiguous(), #t " must be contiguous")
+#define CHECK_BF16(t) do { CHECK_DEV(t); CHECK_CONTIG(t); TORCH_CHECK((t).scalar_type() == at::kBFloat16, #t " must be bf16"); \
+                           TORCH_CHECK(((uintptr_t)(t).data_ptr()) % 16 == 0, #t " must be 16-byte aligned"); } while (0)
+#define CHECK_F32(t) do { CHECK_DEV(t); CHECK_CONTIG(t); TORCH_CHECK((t).scalar_type() == at::kFloat, #t " must be fp32"); } while (0)
+#define CHECK_I64(t) do { CHECK_DEV(t); CHECK_CONTIG(t); TORCH_CHECK((t).scalar_type() == at::kLong, #t " must be int64"); } while (0)
+
+struct Guard {
+    c10::hip::HIPGuard g;
+    explicit Guard(const Tensor& t) : g(t.device()) {}
+};
+
+// ---------------------------------------------------------------- conv
+// x [N,H,W,C] bf16, w [K,R,S,C] bf16 -> y [N,Ho,Wo,K] bf16 (+ optional BN partial stats [rows,2,K])
+std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias, int64_t stride,
+                               int64_t pad, int64_t act, bool want_stats) {
+    CHECK_BF16(x); CHECK_BF16(w);
+    TORCH_CHECK(x.dim() == 4 && w.dim() == 4, "conv_fprop: x and w must be 4-D (NHWC / KRSC)");
+    const int64_t N = x.size(0), H = x.size(1), W = x.size(2), C = x.size(3);
+    const int64_t K = w.size(0), R = w.size(1), S = w.size(2);
+    TORCH_CHECK(w.size(3) == C, "conv_fprop: channel mismatch ", w.size(3), " vs ", C);
+    TORCH_CHECK(C % 8 == 0 && K % 8 == 0, "conv_fprop: C and K must be multiples of 8 (pad channels)");
+    TORCH_CHECK(stride >= 1 && pad >= 0, "bad stride/pad");
+    const int64_t Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    TORCH_CHECK(Ho > 0 && Wo > 0, "conv_fprop: empty output");
+    TORCH_CHECK(N * H * W * C < (1ll << 40) && N * Ho * Wo < (1ll << 31), "conv_fprop: tensor too large");
+    Guard g(x);
+    Tensor y = torch::empty({N, Ho, Wo, K}, x.options());
+    dpa::ConvArgs a{};
+    a.x = x.data_ptr(); a.w = w.data_ptr(); a.y = y.data_ptr();
+    a.bias = nullptr;
+    if (bias.has_value() && bias->defined()) {
+        CHECK_F32((*bias)); TORCH_CHECK(bias->numel() == K, "bias size");
+        TORCH_CHECK(!want_stats, "stats are computed on the bias-free output");
+        a.bias = bias->data_ptr<float>();
+    }
+    Tensor stats;
+    a.stats = nullptr;
+    const int64_t M = N * Ho * Wo;
+    if (want_stats) {
+        stats = torch::empty({dpa::conv_stats_rows(M), 2, K}, x.options().dtype(at::kFloat));
+        a.stats = stats.data_ptr<float>();
+        TORCH_CHECK(act == 0, "stats need a linear epilogue");
+    }
+    a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.Ho = Ho; a.Wo = Wo;
+    a.stride = stride; a.pad = pad; a.mode = 0; a.act = act;
+    dpa::conv_igemm(a, cur_stream());
+    if (want_stats) return {y, stats};
+    return {y};
+}
+
+// dgrad: dy [N,Ho,Wo,K] bf16, wt [C,R,S,K] bf16 (filter with K and C swapped) -> dx [N,H,W,C]
+Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int64_t stride, int64_t pad) {
+    CHECK_BF16(dy); CHECK_BF16(wt);
+    TORCH_CHECK(dy.dim() == 4 && wt.dim() == 4, "conv_dgrad: 4-D tensors expected");
+    const int64_t N = dy.size(0), Ho = dy.size(1), Wo = dy.size(2), K = dy.size(3);
+    const int64_t C = wt.size(0), R = wt.size(1), S = wt.size(2);
+    TORCH_CHECK(wt.size(3) == K, "conv_dgrad: channel mismatch");
+    TORCH_CHECK(C % 8 == 0 && K % 8 == 0, "conv_dgrad: channels must be multiples of 8");
+    TORCH_CHECK((H + 2 * pad - R) / stride + 1 == Ho && (W + 2 * pad - S) / stride + 1 == Wo, "conv_dgrad: geometry mismatch");
+    Guard g(dy);
+    Tensor dx = torch::empty({N, H, W, C}, dy.options());
+    dpa::ConvArgs a{};
+    a.x = dy.data_ptr(); a.w = wt.data_ptr(); a.y = dx.data_ptr(); a.bias = nullptr; a.stats = nullptr;
+    a.N = N; a.H = Ho; a.W = Wo; a.C = K; a.K = C; a.R = R; a.S = S; a.Ho = H; a.Wo = W;
+    a.stride = stride; a.pad = pad; a.mode = 1; a.act = 0;
+    dpa::conv_igemm(a, cur_stream());
+    return dx;
+}
+
+// dw [K,R,S,C] fp32 += wgrad(x, dy).  dw must be initialised by the caller.
+void conv_wgrad(const Tensor& x, const Tensor& dy, Tensor& dw, int64_t stride, int64_t pad) {
+    CHECK_BF16(x); CHECK_BF16(dy); CHECK_F32(dw);
+    TORCH_CHECK(x.dim() == 4 && dy.dim() == 4 && dw.dim() == 4, "conv_wgrad: 4-D tensors expected");
+    const int64_t N = x.size(0), H = x.size(1), W = x.size(2), C = x.size(3);
+    const int64_t Ho = dy.size(1), Wo = dy.size(2), K = dy.size(3);
+    const int64_t R = dw.size(1), S = dw.size(2);
+    TORCH_CHECK(dy.size(0) == N && dw.size(0) == K && dw.size(3) == C, "conv_wgrad: shape mismatch");
+    TORCH_CHECK((H + 2 * pad - R) / stride + 1 == Ho && (W + 2 * pad - S) / stride + 1 == Wo, "conv_wgrad: geometry mismatch");
+    TORCH_CHECK(C % 8 == 0 && K % 8 == 0, "conv_wgrad: channels must be multiples of 8");
+    Guard g(x);
+    dpa::WgradArgs a{};
+    a.x = x.data_ptr(); a.dy = dy.data_ptr(); a.dw = dw.data_ptr<float>();
+    a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = pad;
+    dpa::conv_wgrad(a, cur_stream());
+}
+
+Tensor transpose_filter(const Tensor& w) {
+    CHECK_BF16(w);
+    TORCH_CHECK(w.dim() == 4, "transpose_filter: KRSC expected");
+    Guard g(w);
+    Tensor wt = torch::empty({w.size(3), w.size(1), w.size(2), w.size(0)}, w.options());
+    dpa::transpose_filter(w.data_ptr(), wt.data_ptr(), w.size(0), w.size(1) * w.size(2), w.size(3), cur_stream());
+    return wt;
+}
+
+void colsum(const Tensor& x, Tensor& out) {
+    CHECK_BF16(x); CHECK_F32(out);
+    const int64_t K = x.size(-1);
+    TORCH_CHECK(K % 8 == 0 && out.numel() == K, "colsum: bad shapes");
+    Guard g(x);
+    dpa::colsum_bf16(x.data_ptr(), out.data_ptr<float>(), x.numel() / K, K, cur_stream());
+}
+
+// ---------------------------------------------------------------- batch norm
+Tensor bn_stats(const Tensor& x) {
+    CHECK_BF16(x);
+    const int64_t C = x.size(-1), P = x.numel() / C;
+    TORCH_CHECK(C % 8 == 0 && C <= 2048, "bn_stats: C must be a multiple of 8 and <= 2048");
+    Guard g(x);
+    Tensor stats = torch::empty({dpa::bn_stats_rows(P), 2, C}, x.options().dtype(at::kFloat));
+    dpa::bn_stats(x.data_ptr(), stats.data_ptr<float>(), P, C, cur_stream());
+    return stats;
+}
+
+// stats [rows,2,C] -> (mean, invstd, scale, shift); updates running stats in place
+std::vector<Tensor> bn_finalize(const Tensor& stats_in, int64_t P, const Tensor& gamma, const Tensor& beta,
+                                const c10::optional<Tensor>& running_mean, const c10::optional<Tensor>& running_var,
+                                double momentum, double eps) {
+    CHECK_F32(stats_in); CHECK_F32(gamma); CHECK_F32(beta);
+    TORCH_CHECK(stats_in.dim() == 3 && stats_in.size(1) == 2, "bn_finalize: stats must be [rows,2,C]");
+    const int64_t C = stats_in.size(2);
+    TORCH_CHECK(gamma.numel() == C && beta.numel() == C, "bn_finalize: affine size");
+    Guard g(stats_in);
+    Tensor stats = stats_in;
+    int64_t rows = stats.size(0);
+    if (rows > 256) {  // fold tall partial buffers in parallel first
+        const int chunk = 64;
+        Tensor folded = torch::empty({(rows + chunk - 1) / chunk, 2, C}, stats.options());
+        dpa::fold_rows(stats.data_ptr<float>(), rows, 2 * C, chunk, folded.data_ptr<float>(), cur_stream());
+        stats = folded; rows = folded.size(0);
+    }
+    Tensor out = torch::empty({4, C}, stats.options());
+    float* rm = nullptr; float* rv = nullptr;
+    if (running_mean.has_value() && running_mean->defined()) {
+        CHECK_F32((*running_mean)); CHECK_F32((*running_var));
+        TORCH_CHECK(running_mean->numel() == C && running_var->numel() == C, "running stats size");
+        rm = running_mean->data_ptr<float>(); rv = running_var->data_ptr<float>();
+    }
+    float* o = out.data_ptr<float>();
+    dpa::bn_finalize(stats.data_ptr<float>(), rows, P, C, gamma.data_ptr<float>(), beta.data_ptr<float>(), rm, rv,
+                     (float)momentum, (float)eps, o, o + C, o + 2 * C, o + 3 * C, cur_stream());
+    return {out[0], out[1], out[2], out[3]};
+}
+
+Tensor bn_apply(const Tensor& x, const c10::optional<Tensor>& residual, const Tensor& scale, const Tensor& shift, bool relu) {
+    CHECK_BF16(x); CHECK_F32(scale); CHECK_F32(shift);
+    const int64_t C = x.size(-1), P = x.numel() / C;
+    TORCH_CHECK(C % 8 == 0 && scale.numel() == C && shift.numel() == C, "bn_apply: bad channel count");
+    TORCH_CHECK(((uintptr_t)scale.data_ptr()) % 16 == 0 && ((uintptr_t)shift.data_ptr()) % 16 == 0, "scale/shift alignment");
+    const void* res = nullptr;
+    if (residual.has_value() && residual->defined()) {
+        CHECK_BF16((*residual)); TORCH_CHECK(residual->numel() == x.numel(), "residual shape");
+        res = residual->data_ptr();
+    }
+    Guard g(x);
+    Tensor y = torch::empty_like(x);
+    dpa::bn_apply(x.data_ptr(), res, y.data_ptr(), scale.data_ptr<float>(), shift.data_ptr<float>(), P, C, relu, cur_stream());
+    return y;
+}
+
+// returns (dx, dres or undefined, dgamma, dbeta)
+std::vector<Tensor> bn_backward(const Tensor& dy, const Tensor& y, const Tensor& x, const Tensor& gamma, const Tensor& mean,
+                                const Tensor& invstd, bool relu, bool want_dres) {
+    CHECK_BF16(dy); CHECK_BF16(y); CHECK_BF16(x); CHECK_F32(gamma); CHECK_F32(mean); CHECK_F32(invstd);
+    const int64_t C = x.size(-1), P = x.numel() / C;
+    TORCH_CHECK(dy.numel() == x.numel() && y.numel() == x.numel(), "bn_backward: shape mismatch");
+    TORCH_CHECK(C % 8 == 0 && C <= 2048 && gamma.numel() == C && mean.numel() == C && invstd.numel() == C, "bn_backward: channels");
+    Guard g(x);
+    auto fopt = x.options().dtype(at::kFloat);
+    int rows = dpa::bn_stats_rows(P);
+    Tensor stats = torch::empty({rows, 2, C}, fopt);
+    dpa::bn_bwd_stats(dy.data_ptr(), y.data_ptr(), x.data_ptr(), mean.data_ptr<float>(), invstd.data_ptr<float>(),
+                      stats.data_ptr<float>(), P, C, relu, cur_stream());
+    if (rows > 256) {
+        const int chunk = 64;
+        Tensor folded = torch::empty({(rows + chunk - 1) / chunk, 2, C}, fopt);
+        dpa::fold_rows(stats.data_ptr<float>(), rows, 2 * C, chunk, folded.data_ptr<float>(), cur_stream());
+        stats = folded; rows = folded.size(0);
+    }
+    Tensor co = torch::empty({5, C}, fopt);  // dgamma, dbeta, A, B, C0
+    float* o = co.data_ptr<float>();
+    dpa::bn_bwd_finalize(stats.data_ptr<float>(), rows, P, C, gamma.data_ptr<float>(), mean.data_ptr<float>(),
+                         invstd.data_ptr<float>(), o, o + C, o + 2 * C, o + 3 * C, o + 4 * C, cur_stream());
+    Tensor dx = torch::empty_like(x);
+    Tensor dres;
+    if (want_dres) dres = torch::empty_like(x);
+    dpa::bn_bwd_apply(dy.data_ptr(), y.data_ptr(), x.data_ptr(), o + 2 * C, o + 3 * C, o + 4 * C, dx.data_ptr(),
+                      want_dres ? dres.data_ptr() : nullptr, P, C, relu, cur_stream());
+    return {dx, dres, co[0], co[1]};
+}
+
+// ---------------------------------------------------------------- pooling / layout / elementwise
+std::vector<Tensor> maxpool_fwd(const Tensor& x) {
+    CHECK_BF16(x); TORCH_CHECK(x.dim() == 4 && x.size(3) % 8 == 0, "maxpool: NHWC with C % 8 == 0");
+    const int64_t N = x.size(0), H = x.size(1), W = x.size(2), C = x.size(3);
+    const int64_t Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    Guard g(x);
+    Tensor y = torch::empty({N, Ho, Wo, C}, x.options());
+    Tensor idx = torch::empty({N, Ho, Wo, C}, x.options().dtype(at::kByte));
+    dpa::maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr<uint8_t>(), N, H, W, C, Ho, Wo, cur_stream());
+    return {y, idx};
+}
+
+Tensor maxpool_bwd(const Tensor& dy, const Tensor& idx, int64_t H, int64_t W) {
+    CHECK_BF16(dy); CHECK_DEV(idx); CHECK_CONTIG(idx);
+    TORCH_CHECK(idx.scalar_type() == at::kByte && idx.numel() == dy.numel(), "maxpool_bwd: idx");
+    const int64_t N = dy.size(0), Ho = dy.size(1), Wo = dy.size(2), C = dy.size(3);
+    TORCH_CHECK((H - 1) / 2 + 1 == Ho && (W - 1) / 2 + 1 == Wo, "maxpool_bwd: geometry");
+    Guard g(dy);
+    Tensor dx = torch::empty({N, H, W, C}, dy.options());
+    dpa::maxpool3x3s2_bwd(dy.data_ptr(), idx.data_ptr<uint8_t>(), dx.data_ptr(), N, H, W, C, Ho, Wo, cur_stream());
+    return dx;
+}
+
+Tensor avgpool_fwd(const Tensor& x) {
+    CHECK_BF16(x); TORCH_CHECK(x.dim() == 4 && x.size(3) % 8 == 0, "avgpool: NHWC with C % 8 == 0");
+    Guard g(x);
+    Tensor y = torch::empty({x.size(0), x.size(3)}, x.options());
+    dpa::avgpool_fwd(x.data_ptr(), y.data_ptr(), x.size(0), x.size(1) * x.size(2), x.size(3), cur_stream());
+    return y;
+}
+
+Tensor avgpool_bwd(const Tensor& dy, int64_t H, int64_t W) {
+    CHECK_BF16(dy); TORCH_CHECK(dy.dim() == 2 && dy.size(1) % 8 == 0, "avgpool_bwd: [N,C]");
+    Guard g(dy);
+    Tensor dx = torch::empty({dy.size(0), H, W, dy.size(1)}, dy.options());
+    dpa::avgpool_bwd(dy.data_ptr(), dx.data_ptr(), dy.size(0), H * W, dy.size(1), cur_stream());
+    return dx;
+}
+
+Tensor nchw_to_nhwc_pad(const Tensor& x, int64_t Cpad) {
+    CHECK_DEV(x); CHECK_CONTIG(x);
+    TORCH_CHECK(x.dim() == 4, "NCHW expected");
+    TORCH_CHECK(x.scalar_type() == at::kFloat || x.scalar_type() == at::kBFloat16, "fp32 or bf16 input");
+    TORCH_CHECK(Cpad % 8 == 0 && Cpad >= x.size(1), "Cpad");
+    Guard g(x);
+    Tensor y = torch::empty({x.size(0), x.size(2), x.size(3), Cpad}, x.options().dtype(at::kBFloat16));
+    dpa::nchw_to_nhwc_pad(x.data_ptr(), x.scalar_type() == at::kBFloat16, y.data_ptr(), x.size(0), x.size(1), x.size(2),
+                          x.size(3), Cpad, cur_stream());
+    return y;
+}
+
+Tensor ew2(const Tensor& a, const Tensor& b, int64_t op) {
+    CHECK_BF16(a); CHECK_BF16(b); TORCH_CHECK(a.numel() == b.numel(), "elementwise: size mismatch");
+    Guard g(a);
+    Tensor y = torch::empty_like(a);
+    const long n = a.numel();
+    switch (op) {
+        case 0: dpa::add_bf16(a.data_ptr(), b.data_ptr(), y.data_ptr(), n, cur_stream()); break;
+        case 1: dpa::add_relu_fwd(a.data_ptr(), b.data_ptr(), y.data_ptr(), n, cur_stream()); break;
+        case 2: dpa::relu_bwd(a.data_ptr(), b.data_ptr(), y.data_ptr(), n, cur_stream()); break;
+        case 3: dpa::gelu_fwd(a.data_ptr(), y.data_ptr(), n, cur_stream()); break;
+        case 4: dpa::gelu_bwd(a.data_ptr(), b.data_ptr(), y.data_ptr(), n, cur_stream()); break;
+        default: TORCH_CHECK(false, "unknown elementwise op");
+    }
+    return y;
+}
+
+// ---------------------------------------------------------------- loss
+// returns (loss_sum_scaled [1] fp32, lse [B] fp32)
+std::vector<Tensor> softmax_ce_fwd(const Tensor& logits, const Tensor& targets, int64_t V, double scale, int64_t ignore_index) {
+    CHECK_DEV(logits); CHECK_CONTIG(logits); CHECK_I64(targets);
+    TORCH_CHECK(logits.dim() == 2, "logits must be [B, ld]");
+    const bool bf = logits.scalar_type() == at::kBFloat16;
+    TORCH_CHECK(bf || logits.scalar_type() == at::kFloat, "logits must be bf16 or fp32");
+    const int64_t B = logits.size(0), ld = logits.size(1);
+    TORCH_CHECK(V >= 1 && V <= ld && targets.numel() == B, "softmax_ce: shapes");
+    Guard g(logits);
+    auto fopt = logits.options().dtype(at::kFloat);
+    Tensor loss = torch::zeros({1}, fopt), lse = torch::empty({B}, fopt);
+    dpa::softmax_ce_fwd(logits.data_ptr(), bf, targets.data_ptr<int64_t>(), lse.data_ptr<float>(), loss.data_ptr<float>(),
+                        B, V, ld, (float)scale, ignore_index, cur_stream());
+    return {loss, lse};
+}
+
+Tensor softmax_ce_bwd(const Tensor& logits, const Tensor& targets, const Tensor& lse, const Tensor& gscale, int64_t V,
+                      double scale, int64_t ignore_index, bool inplace) {
+    CHECK_DEV(logits); CHECK_CONTIG(logits); CHECK_I64(targets); CHECK_F32(lse); CHECK_F32(gscale);
+    const bool bf = logits.scalar_type() == at::kBFloat16;
+    TORCH_CHECK(bf || logits.scalar_type() == at::kFloat, "logits must be bf16 or fp32");
+    const int64_t B = logits.size(0), ld = logits.size(1);
+    TORCH_CHECK(V >= 1 && V <= ld && targets.numel() == B && lse.numel() == B && gscale.numel() == 1, "softmax_ce_bwd: shapes");
+    Guard g(logits);
+    Tensor d = inplace ? logits : torch::empty_like(logits);
+    dpa::softmax_ce_bwd(logits.data_ptr(), bf, targets.data_ptr<int64_t>(), lse.data_ptr<float>(), gscale.data_ptr<float>(),
+                        d.data_ptr(), B, V, ld, (float)scale, ignore_index, cur_stream());
+    return d;
+}
+
+// ---------------------------------------------------------------- optimizer / casts
+void sgd_momentum(Tensor& p, Tensor& grad, const c10::optional<Tensor>& m, const c10::optional<Tensor>& p_lp, double lr,
+                  double mu, double wd, double grad_scale, bool zero_grad, bool nesterov) {
+    CHECK_F32(p); CHECK_F32(grad);
+    const int64_t n = p.numel();
+    TORCH_CHECK(grad.numel() == n, "sgd: grad size");
+    TORCH_CHECK(((uintptr_t)p.data_ptr()) % 16 == 0 && ((uintptr_t)grad.data_ptr()) % 16 == 0, "sgd: 16-byte alignment");
+    float* mp = nullptr; void* lp = nullptr;
+    if (mu != 0.0) {
+        TORCH_CHECK(m.has_value() && m->defined(), "sgd: momentum buffer required");
+        CHECK_F32((*m)); TORCH_CHECK(m->numel() == n && ((uintptr_t)m->data_ptr()) % 16 == 0, "sgd: momentum buffer");
+        mp = m->data_ptr<float>();
+    }
+    if (p_lp.has_value() && p_lp->defined()) {
+        CHECK_DEV((*p_lp)); CHECK_CONTIG((*p_lp));
+        TORCH_CHECK(p_lp->scalar_type() == at::kBFloat16 && p_lp->numel() == n && ((uintptr_t)p_lp->data_ptr()) % 8 == 0, "sgd: bf16 shadow");
+        lp = p_lp->data_ptr();
+    }
+    Guard g(p);
+    dpa::sgd_momentum(p.data_ptr<float>(), grad.data_ptr<float>(), mp, lp, n, (float)lr, (float)mu, (float)wd,
+                      (float)grad_scale, zero_grad, nesterov, cur_stream());
+}
+
+void adamw(Tensor& p, Tensor& grad, Tensor& m, Tensor& v, const c10::optional<Tensor>& p_lp, double lr, double b1, double b2,
+           double eps, double wd, double grad_scale, int64_t step, bool zero_grad) {
+    CHECK_F32(p); CHECK_F32(grad); CHECK_F32(m); CHECK_F32(v);
+    const int64_t n = p.numel();
+    TORCH_CHECK(grad.numel() == n && m.numel() == n && v.numel() == n, "adamw: sizes");
+    void* lp = nullptr;
+    if (p_lp.has_value() && p_lp->defined()) {
+        CHECK_DEV((*p_lp)); CHECK_CONTIG((*p_lp));
+        TORCH_CHECK(p_lp->scalar_type() == at::kBFloat16 && p_lp->numel() == n, "adamw: bf16 shadow");
+        lp = p_lp->data_ptr();
+    }
+    Guard g(p);
+    const double bc1 = 1.0 - std::pow(b1, (double)step), bc2 = 1.0 - std::pow(b2, (double)step);
+    dpa::adamw(p.data_ptr<float>(), grad.data_ptr<float>(), m.data_ptr<float>(), v.data_ptr<float>(), lp, n, (float)lr,
+               (float)b1, (float)b2, (float)eps, (float)wd, (float)grad_scale, (float)bc1, (float)bc2, zero_grad, cur_stream());
+}
+
+void cast_f32_to_bf16(const Tensor& x, Tensor& y) {
+    CHECK_F32(x); CHECK_DEV(y); CHECK_CONTIG(y);
+    TORCH_CHECK(y.scalar_type() == at::kBFloat16 && y.numel() == x.numel(), "cast: shapes");
+    Guard g(x);
+    dpa::cast_f32_to_bf16(x.data_ptr<float>(), y.data_ptr(), x.numel(), cur_stream());
+}
+
+Tensor cast_bf16_to_f32(const Tensor& x) {
+    CHECK_DEV(x); CHECK_CONTIG(x); TORCH_CHECK(x.scalar_type() == at::kBFloat16, "bf16 expected");
+    Guard g(x);
+    Tensor y = torch::empty(x.sizes(), x.options().dtype(at::kFloat));
+    dpa::cast_bf16_to_f32(x.data_ptr(), y.data_ptr<float>(), x.numel(), cur_stream());
+    return y;
+}
+
+// ---------------------------------------------------------------- MNIST nets (fp32 NCHW)
+std::vector<Tensor> conv5_pool_relu_fwd(const Tensor& x, const Tensor& w, const Tensor& b, const c10::optional<Tensor>& drop) {
+    CHECK_F32(x); CHECK_F32(w); CHECK_F32(b);
+    TORCH_CHECK(x.dim() == 4 && w.dim() == 4 && w.size(2) == 5 && w.size(3) == 5 && w.size(1) == x.size(1), "conv5: shapes");
+    const int64_t N = x.size(0), Cin = x.size(1), H = x.size(2), W = x.size(3), Cout = w.size(0);
+    TORCH_CHECK(H >= 6 && W >= 6 && (H - 4) % 2 == 0 && (W - 4) % 2 == 0 && b.numel() == Cout, "conv5: geometry");
+    const float* dm = nullptr;
+    if (drop.has_value() && drop->defined()) { CHECK_F32((*drop)); TORCH_CHECK(drop->numel() == N * Cout, "drop mask"); dm = drop->data_ptr<float>(); }
+    Guard g(x);
+    Tensor y = torch::empty({N, Cout, (H - 4) / 2, (W - 4) / 2}, x.options());
+    Tensor idx = torch::empty(y.sizes(), x.options().dtype(at::kByte));
+    dpa::conv5_pool_relu_fwd(x.data_ptr<float>(), w.data_ptr<float>(), b.data_ptr<float>(), y.data_ptr<float>(),
+                             idx.data_ptr<uint8_t>(), N, Cin, H, W, Cout, dm, cur_stream());
+    return {y, idx};
+}
+
+std::vector<Tensor> conv5_pool_relu_bwd(const Tensor& x, const Tensor& w, const Tensor& dy, const Tensor& y, const Tensor& idx,
+                                        const c10::optional<Tensor>& drop, bool need_dx) {
+    CHECK_F32(x); CHECK_F32(w); CHECK_F32(dy); CHECK_F32(y); CHECK_DEV(idx); CHECK_CONTIG(idx);
+    const int64_t N = x.size(0), Cin = x.size(1), H = x.size(2), W = x.size(3), Cout = w.size(0);
+    TORCH_CHECK(dy.numel() == y.numel() && idx.numel() == y.numel() && idx.scalar_type() == at::kByte, "conv5 bwd: shapes");
+    TORCH_CHECK(y.numel() == N * Cout * ((H - 4) / 2) * ((W - 4) / 2), "conv5 bwd: geometry");
+    const float* dm = nullptr;
+    if (drop.has_value() && drop->defined()) { CHECK_F32((*drop)); dm = drop->data_ptr<float>(); }
+    Guard g(x);
+    Tensor dw = torch::empty_like(w), db = torch::empty({Cout}, w.options()), dx;
+    if (need_dx) dx = torch::empty_like(x);
+    dpa::conv5_pool_relu_bwd(x.data_ptr<float>(), w.data_ptr<float>(), dy.data_ptr<float>(), y.data_ptr<float>(),
+                             idx.data_ptr<uint8_t>(), need_dx ? dx.data_ptr<float>() : nullptr, dw.data_ptr<float>(),
+                             db.data_ptr<float>(), N, Cin, H, W, Cout, dm, cur_stream());
+    return {dx, dw, db};
+}
+
+Tensor linear_f32_fwd(const Tensor& x, const Tensor& w, const Tensor& b, bool relu) {
+    CHECK_F32(x); CHECK_F32(w); CHECK_F32(b);
+    TORCH_CHECK(x.dim() == 2 && w.dim() == 2 && w.size(1) == x.size(1) && b.numel() == w.size(0), "linear_f32: shapes");
+    Guard g(x);
+    Tensor y = torch::empty({x.size(0), w.size(0)}, x.options());
+    dpa::linear_f32_fwd(x.data_ptr<float>(), w.data_ptr<float>(), b.data_ptr<float>(), y.data_ptr<float>(), x.size(0),
+                        x.size(1), w.size(0), relu, cur_stream());
+    return y;
+}
+
+std::vector<Tensor> linear_f32_bwd(const Tensor& x, const Tensor& w, const Tensor& y, const Tensor& dy, bool relu, bool need_dx) {
+    CHECK_F32(x); CHECK_F32(w); CHECK_F32(y); CHECK_F32(dy);
+    TORCH_CHECK(dy.sizes() == y.sizes() && y.size(0) == x.size(0) && y.size(1) == w.size(0), "linear_f32 bwd: shapes");
+    Guard g(x);
+    Tensor dw = torch::empty_like(w), db = torch::empty({w.size(0)}, w.options()), dx;
+    if (need_dx) dx = torch::empty_like(x);
+    dpa::linear_f32_bwd(x.data_ptr<float>(), w.data_ptr<float>(), y.data_ptr<float>(), dy.data_ptr<float>(),
+                        need_dx ? dx.data_ptr<float>() : nullptr, dw.data_ptr<float>(), db.data_ptr<float>(), x.size(0),
+                        x.size(1), w.size(0), relu, cur_stream());
+    return {dx, dw, db};
+}
+
+Tensor log_softmax_fwd(const Tensor& x) {
+    CHECK_F32(x); TORCH_CHECK(x.dim() == 2, "log_softmax: 2-D");
+    Guard g(x);
+    Tensor y = torch::empty_like(x);
+    dpa::log_softmax_fwd(x.data_ptr<float>(), y.data_ptr<float>(), x.size(0), x.size(1), cur_stream());
+    return y;
+}
+Tensor log_softmax_bwd(const Tensor& dy, const Tensor& y) {
+    CHECK_F32(dy); CHECK_F32(y); TORCH_CHECK(dy.sizes() == y.sizes(), "log_softmax bwd: shapes");
+    Guard g(y);
+    Tensor dx = torch::empty_like(y);
+    dpa::log_softmax_bwd(dy.data_ptr<float>(), y.data_ptr<float>(), dx.data_ptr<float>(), y.size(0), y.size(1), cur_stream());
+    return dx;
+}
+Tensor nll_fwd(const Tensor& logp, const Tensor& t) {
+    CHECK_F32(logp); CHECK_I64(t); TORCH_CHECK(logp.dim() == 2 && t.numel() == logp.size(0), "nll: shapes");
+    Guard g(logp);
+    Tensor loss = torch::empty({}, logp.options());
+    dpa::nll_fwd(logp.data_ptr<float>(), t.data_ptr<int64_t>(), loss.data_ptr<float>(), logp.size(0), logp.size(1), cur_stream());
+    return loss;
+}
+Tensor nll_bwd(const Tensor& gout, const Tensor& t, int64_t rows, int64_t V) {
+    CHECK_F32(gout); CHECK_I64(t); TORCH_CHECK(gout.numel() == 1 && t.numel() == rows, "nll bwd: shapes");
+    Guard g(gout);
+    Tensor d = torch::empty({rows, V}, gout.options());
+    dpa::nll_bwd(gout.data_ptr<float>(), t.data_ptr<int64_t>(), d.data_ptr<float>(), rows, V, cur_stream());
+    return d;
+}
+Tensor dropout_mask(int64_t n, double p, int64_t seed, int64_t offset, const Tensor& like) {
+    CHECK_DEV(like);
+    Guard g(like);
+    Tensor m = torch::empty({n}, like.options().dtype(at::kFloat));
+    dpa::dropout_mask(m.data_ptr<float>(), n, (float)p, (uint64_t)seed, (uint64_t)offset, cur_stream());
+    return m;
+}
+Tensor mul_f32(const Tensor& a, const Tensor& b) {
+    CHECK_F32(a); CHECK_F32(b); TORCH_CHECK(a.numel() == b.numel(), "mul: sizes");
+    Guard g(a);
+    Tensor y = torch::empty_like(a);
+    dpa::mul_f32(a.data_ptr<float>(), b.data_ptr<float>(), y.data_ptr<float>(), a.numel(), cur_stream());
+    return y;
+}
+
+}  // namespace
+
+void bind_transformer(pybind11::module_& m);  // bindings_tfm.cpp
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "distributedpytorch_amd gfx950 kernels";
+    m.def("conv_fprop", &conv_fprop);
+    m.def("conv_dgrad", &conv_dgrad);
+    m.def("conv_wgrad", &conv_wgrad);
+    m.def("transpose_filter", &transpose_filter);
+    m.def("colsum", &colsum);
+    m.def("bn_stats", &bn_stats);
+    m.def("bn_finalize", &bn_finalize);
+    m.def("bn_apply", &bn_apply);
+    m.def("bn_backward", &bn_backward);
+    m.def("maxpool_fwd", &maxpool_fwd);
+    m.def("maxpool_bwd", &maxpool_bwd);
+    m.def("avgpool_fwd", &avgpool_fwd);
+    m.def("avgpool_bwd", &avgpool_bwd);
+    m.def("nchw_to_nhwc_pad", &nchw_to_nhwc_pad);
+    m.def("ew2", &ew2);
+    m.def("softmax_ce_fwd", &softmax_ce_fwd);
+    m.def("softmax_ce_bwd", &softmax_ce_bwd);
+    m.def("sgd_momentum", &sgd_momentum);
+    m.def("adamw", &adamw);
+    m.def("cast_f32_to_bf16", &cast_f32_to_bf16);
+    m.def("cast_bf16_to_f32", &cast_bf16_to_f32);
+    m.def("conv5_pool_relu_fwd", &conv5_pool_relu_fwd);
+    m.def("conv5_pool_relu_bwd", &conv5_pool_relu_bwd);
+    m.def("linear_f32_fwd", &linear_f32_fwd);
+    m.def("linear_f32_bwd", &linear_f32_bwd);
+    m.def("log_softmax_fwd", &log_softmax_fwd);
+    m.def("log_softmax_bwd", &log_softmax_bwd);
+    m.def("nll_fwd", &nll_fwd);
+    m.def("nll_bwd", &nll_bwd);
+    m.def("dropout_mask", &dropout_mask);
+    m.def("mul_f32", &mul_f32);
+    bind_transformer(m);
+}

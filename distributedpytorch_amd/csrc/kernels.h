@@ -108,8 +108,8 @@ void layernorm_bwd(const void* dy, const void* x, const float* g, const float* m
                    void* dx, float* dg_partial, float* db_partial, int partial_rows, long rows, int C, hipStream_t st);
 int layernorm_partial_rows(long rows);
 void reduce_partials(const float* partial, int rows, int C, float* out, int accumulate, hipStream_t st);
-void embedding_fwd(const int64_t* tok, const void* wte, const void* wpe, void* y, long B, int T, int C, hipStream_t st);
-void embedding_bwd(const int64_t* tok, const void* dy, float* dwte, float* dwpe, long B, int T, int C, hipStream_t st);
+void embedding_fwd(const int64_t* tok, const void* wte, const void* wpe, void* y, long B, int T, int C, long V, hipStream_t st);
+void embedding_bwd(const int64_t* tok, const void* dy, float* dwte, float* dwpe, long B, int T, int C, long V, hipStream_t st);
 // causal flash attention, qkv packed [B, T, 3, H, D] bf16, D = 64
 void attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int D, hipStream_t st);
 void attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,

@@ -1,0 +1,219 @@
+// LayerNorm, embedding and partial-reduction kernels for the GPT-2 path (gfx950).
+// Memory-bound: one 64-lane wave per row, 16 B (8 bf16) per lane, wave shuffles
+// for the row reductions; parameter gradients are reduced per block in LDS and
+// written as partial rows (no atomics), then folded by reduce_partials.
+#include "common.h"
+#include "kernels.h"
+
+namespace dpa {
+namespace {
+
+constexpr int LN_MAX_CHUNKS = 4;  // per lane -> C <= 64*8*4 = 2048
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const unsigned short* __restrict__ x, const float* __restrict__ g,
+                                                            const float* __restrict__ b, unsigned short* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, long rows,
+                                                            int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = C / 8;
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const unsigned short* xr = x + row * C;
+        float v[LN_MAX_CHUNKS][8];
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+            const int ch = lane + k * 64;
+            if (ch < nch) {
+                uint4 u = *(const uint4*)(xr + ch * 8);
+                unpack8(u, v[k]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s += v[k][j]; q += v[k][j] * v[k][j]; }
+            }
+        }
+        s = wave_reduce_sum(s); q = wave_reduce_sum(q);
+        const float m = s / (float)C;
+        float var = q / (float)C - m * m;
+        var = var < 0.f ? 0.f : var;
+        const float rs = rsqrtf(var + eps);
+        if (lane == 0) { mean[row] = m; rstd[row] = rs; }
+#pragma unroll
+        for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+            const int ch = lane + k * 64;
+            if (ch < nch) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (v[k][j] - m) * rs * g[ch * 8 + j] + b[ch * 8 + j];
+                *(uint4*)(y + row * C + ch * 8) = pack8(o);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
+                                                            const float* __restrict__ g, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, unsigned short* __restrict__ dx,
+                                                            float* __restrict__ dg_part, float* __restrict__ db_part,
+                                                            long rows, int C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = C / 8;
+    float dg[LN_MAX_CHUNKS][8], db[LN_MAX_CHUNKS][8];
+#pragma unroll
+    for (int k = 0; k < LN_MAX_CHUNKS; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dg[k][j] = 0.f; db[k][j] = 0.f; }
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const float m = mean[row], rs = rstd[row];
+        float xh[LN_MAX_CHUNKS][8], gy[LN_MAX_CHUNKS][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+            const int ch = lane + k * 64;
+            if (ch < nch) {
+                float d[8], xv[8];
+                { uint4 u = *(const uint4*)(dy + row * C + ch * 8); unpack8(u, d); }
+                { uint4 u = *(const uint4*)(x + row * C + ch * 8); unpack8(u, xv); }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float h = (xv[j] - m) * rs;
+                    xh[k][j] = h;
+                    dg[k][j] += d[j] * h; db[k][j] += d[j];
+                    const float t = d[j] * g[ch * 8 + j];
+                    gy[k][j] = t;
+                    s1 += t; s2 += t * h;
+                }
+            }
+        }
+        s1 = wave_reduce_sum(s1) / (float)C; s2 = wave_reduce_sum(s2) / (float)C;
+#pragma unroll
+        for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+            const int ch = lane + k * 64;
+            if (ch < nch) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = rs * (gy[k][j] - s1 - xh[k][j] * s2);
+                *(uint4*)(dx + row * C + ch * 8) = pack8(o);
+            }
+        }
+    }
+    // fold the 4 waves of the block through LDS, then one partial row per block
+    __shared__ float red[4][64 * 8 + 8];
+    for (int pass = 0; pass < 2 * LN_MAX_CHUNKS; ++pass) {
+        const int k = pass >> 1;
+        const bool is_g = (pass & 1) == 0;
+        const int ch = lane + k * 64;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = is_g ? dg[k][j] : db[k][j];
+        __syncthreads();
+        if (wave == 0 && ch < nch) {
+            float* outp = (is_g ? dg_part : db_part) + (long)blockIdx.x * C + ch * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                outp[j] = red[0][lane * 8 + j] + red[1][lane * 8 + j] + red[2][lane * 8 + j] + red[3][lane * 8 + j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int rows, int C,
+                                                              float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += part[(long)r * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __restrict__ tok, const unsigned short* __restrict__ wte,
+                                                            const unsigned short* __restrict__ wpe, unsigned short* __restrict__ y,
+                                                            long BT, int T, int C, long V) {
+    const int nch = C / 8;
+    const long total = BT * nch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        const long row = i / nch;
+        const int t = (int)(row % T);
+        long id = tok[row];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        float a[8], p[8];
+        { uint4 u = *(const uint4*)(wte + id * C + ch * 8); unpack8(u, a); }
+        { uint4 u = *(const uint4*)(wpe + (long)t * C + ch * 8); unpack8(u, p); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += p[j];
+        *(uint4*)(y + i * 8) = pack8(a);
+    }
+}
+
+__global__ __launch_bounds__(256) void embedding_bwd_tok_kernel(const int64_t* __restrict__ tok, const unsigned short* __restrict__ dy,
+                                                                float* __restrict__ dwte, long BT, int C, long V) {
+    // one wave-instruction adds 64 consecutive floats (256 contiguous bytes) of one row
+    const long total = BT * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long row = i / C;
+        const int c = (int)(i - row * C);
+        long id = tok[row];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        atomicAdd(dwte + id * C + c, bf16_to_float(dy[i]));
+    }
+}
+
+__global__ __launch_bounds__(256) void embedding_bwd_pos_kernel(const unsigned short* __restrict__ dy, float* __restrict__ dwpe,
+                                                                long B, int T, int C) {
+    const int nch = C / 8;
+    const long total = (long)T * nch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        const long t = i / nch;
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (long b = 0; b < B; ++b) {
+            uint4 u = *(const uint4*)(dy + ((b * T + t) * C) + ch * 8);
+            float f[8]; unpack8(u, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += f[j];
+        }
+        float* o = dwpe + t * C + ch * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += s[j];
+    }
+}
+
+inline int grid_for(long n) { long b = (n + 255) / 256; if (b > 4096) b = 4096; if (b < 1) b = 1; return (int)b; }
+
+}  // namespace
+
+int layernorm_partial_rows(long rows) {
+    long b = (rows + 3) / 4;
+    if (b > 512) b = 512;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+void layernorm_fwd(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd,
+                   long rows, int C, float eps, hipStream_t st) {
+    long blocks = (rows + 3) / 4; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const unsigned short*)x, g, b,
+                       (unsigned short*)y, mean, rstd, rows, C, eps);
+}
+
+void layernorm_bwd(const void* dy, const void* x, const float* g, const float* mean, const float* rstd,
+                   void* dx, float* dg_partial, float* db_partial, int partial_rows, long rows, int C, hipStream_t st) {
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(partial_rows), dim3(256), 0, st, (const unsigned short*)dy,
+                       (const unsigned short*)x, g, mean, rstd, (unsigned short*)dx, dg_partial, db_partial, rows, C);
+}
+
+void reduce_partials(const float* partial, int rows, int C, float* out, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, rows, C, out, accumulate);
+}
+
+void embedding_fwd(const int64_t* tok, const void* wte, const void* wpe, void* y, long B, int T, int C, long V, hipStream_t st) {
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid_for(B * T * (C / 8))), dim3(256), 0, st, tok, (const unsigned short*)wte,
+                       (const unsigned short*)wpe, (unsigned short*)y, B * T, T, C, V);
+}
+
+void embedding_bwd(const int64_t* tok, const void* dy, float* dwte, float* dwpe, long B, int T, int C, long V, hipStream_t st) {
+    hipLaunchKernelGGL(embedding_bwd_tok_kernel, dim3(grid_for(B * T * C)), dim3(256), 0, st, tok, (const unsigned short*)dy,
+                       dwte, B * T, C, V);
+    hipLaunchKernelGGL(embedding_bwd_pos_kernel, dim3(grid_for((long)T * (C / 8))), dim3(256), 0, st,
+                       (const unsigned short*)dy, dwpe, B, T, C);
+}
+
+}  // namespace dpa

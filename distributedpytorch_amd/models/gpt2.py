@@ -1,0 +1,146 @@
+"""GPT-2 (small = 124M) on the gfx950 kernels: BASELINE.json config 5.
+
+Not in the reference.  Parameter names follow the HuggingFace ``GPT2Model`` layout
+(``wte wpe h.N.ln_1 h.N.attn.c_attn h.N.attn.c_proj h.N.ln_2 h.N.mlp.c_fc
+h.N.mlp.c_proj ln_f``); ``checkpoint.py`` transposes the ``Conv1D`` weights at the
+save/load edge.  All GEMMs (QKV, proj, MLP, tied LM head) run on the implicit-GEMM
+MFMA kernel in bf16 with fp32 accumulation; attention is the causal flash kernel;
+LayerNorm / GELU / residual adds are streaming kernels; the 50,257-class softmax
+cross-entropy is fused and its backward runs in place over the logits.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..nn import Linear, LayerNorm
+
+
+@dataclass
+class GPT2Config:
+    vocab_size: int = 50257
+    n_positions: int = 1024
+    n_embd: int = 768
+    n_layer: int = 12
+    n_head: int = 12
+
+    @property
+    def vocab_padded(self) -> int:
+        return (self.vocab_size + 63) // 64 * 64
+
+
+class Attention(nn.Module):
+    def __init__(self, cfg: GPT2Config):
+        super().__init__()
+        self.n_head = cfg.n_head
+        self.c_attn = Linear(cfg.n_embd, 3 * cfg.n_embd, init_std=0.02)
+        self.c_proj = Linear(cfg.n_embd, cfg.n_embd, init_std=0.02 / math.sqrt(2 * cfg.n_layer))
+
+    def forward(self, x):
+        return self.c_proj(ops.causal_attention(self.c_attn(x), self.n_head))
+
+
+class MLP(nn.Module):
+    def __init__(self, cfg: GPT2Config):
+        super().__init__()
+        self.c_fc = Linear(cfg.n_embd, 4 * cfg.n_embd, init_std=0.02)
+        self.c_proj = Linear(4 * cfg.n_embd, cfg.n_embd, init_std=0.02 / math.sqrt(2 * cfg.n_layer))
+
+    def forward(self, x):
+        return self.c_proj(ops.gelu(self.c_fc(x)))
+
+
+class Block(nn.Module):
+    def __init__(self, cfg: GPT2Config):
+        super().__init__()
+        self.ln_1 = LayerNorm(cfg.n_embd)
+        self.attn = Attention(cfg)
+        self.ln_2 = LayerNorm(cfg.n_embd)
+        self.mlp = MLP(cfg)
+
+    def forward(self, x):
+        x = ops.add(x, self.attn(self.ln_1(x)))
+        return ops.add(x, self.mlp(self.ln_2(x)))
+
+
+class Embedding(nn.Module):
+    """Holds ``wte`` / ``wpe`` (fp32 masters + bf16 shadows)."""
+
+    def __init__(self, cfg: GPT2Config):
+        super().__init__()
+        wte = torch.zeros(cfg.vocab_padded, cfg.n_embd)
+        wte[: cfg.vocab_size].normal_(0.0, 0.02)
+        self.wte = nn.Parameter(wte)
+        self.wte._dpa_uses = 2            # embedding gather + tied LM head both add into its gradient
+        self.wpe = nn.Parameter(torch.randn(cfg.n_positions, cfg.n_embd) * 0.01)
+        self.wte_lp = None
+        self.wpe_lp = None
+
+    def forward(self, tokens):
+        x = ops.embedding(tokens, self.wte, self.wpe, self.wte_lp, self.wpe_lp)
+        if x.is_cuda and x.dtype != torch.bfloat16:
+            x = x.to(torch.bfloat16)
+        return x
+
+
+class GPT2(nn.Module):
+    def __init__(self, cfg: GPT2Config = GPT2Config()):
+        super().__init__()
+        self.cfg = cfg
+        self.emb = Embedding(cfg)
+        self.h = nn.ModuleList([Block(cfg) for _ in range(cfg.n_layer)])
+        self.ln_f = LayerNorm(cfg.n_embd)
+
+    def hidden(self, tokens: torch.Tensor) -> torch.Tensor:
+        x = self.emb(tokens)
+        for blk in self.h:
+            x = blk(x)
+        return self.ln_f(x)
+
+    def forward(self, tokens: torch.Tensor) -> torch.Tensor:
+        """Logits ``[B, T, vocab_padded]`` (tied LM head; columns >= vocab_size are padding)."""
+        x = self.hidden(tokens)
+        return ops.linear(x, self.emb.wte, self.emb.wte_lp, None)
+
+    def loss(self, tokens: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        logits = self.forward(tokens)
+        return ops.softmax_cross_entropy(logits.reshape(-1, logits.shape[-1]), targets.reshape(-1),
+                                         self.cfg.vocab_size, inplace_backward=True)
+
+    def pipeline_layers(self) -> List[nn.Module]:
+        return [self.emb, *self.h, _LMHead(self)]
+
+
+class _LMHead(nn.Module):
+    """ln_f + tied head as a pipeline unit (shares ``wte`` with the embedding stage; only
+    valid when both live on the same stage or the tie is dropped)."""
+
+    def __init__(self, model: GPT2):
+        super().__init__()
+        self.ln_f = model.ln_f
+        self._model = [model]
+
+    def forward(self, x):
+        m = self._model[0]
+        return ops.linear(self.ln_f(x), m.emb.wte, m.emb.wte_lp, None)
+
+
+def gpt2_small() -> GPT2:
+    return GPT2(GPT2Config())
+
+
+def gpt2_tiny(n_layer: int = 2, n_embd: int = 128, n_head: int = 2, vocab: int = 500, n_positions: int = 128) -> GPT2:
+    return GPT2(GPT2Config(vocab_size=vocab, n_positions=n_positions, n_embd=n_embd, n_layer=n_layer, n_head=n_head))
+
+
+def flops_per_token(cfg: GPT2Config, seq_len: int) -> float:
+    """Training FLOPs per token (fwd+bwd = 3x forward), dense GEMMs + causal attention."""
+    c, l = cfg.n_embd, cfg.n_layer
+    gemm = 2.0 * l * (3 * c * c + c * c + 8 * c * c) + 2.0 * c * cfg.vocab_padded
+    attn = 2.0 * l * 2 * seq_len * c / 2.0
+    return 3.0 * (gemm + attn)

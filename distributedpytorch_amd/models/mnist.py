@@ -1,0 +1,97 @@
+"""The reference's MNIST networks on the fused fp32 kernels.
+
+``Net`` (multinode-DP/multinodeDP.py:77-95), ``Net1`` / ``Net2`` (the two model-parallel
+stages, multinode-MP/multinodeMP.py:76-100).  Attribute names - and therefore
+``state_dict`` keys, shapes (OIHW) and dtypes - are exactly the reference's
+(``conv1 conv2 conv2_drop fc1 fc2``), so a checkpoint moves freely between the stock
+PyTorch model and this one, and ``Net1`` + ``Net2`` together load into ``Net``.
+The ``nn.Conv2d`` / ``nn.Linear`` members are used as parameter containers only;
+the math runs in ``ops.conv5_pool_relu`` / ``ops.linear_f32`` (one fused kernel per
+layer) instead of cuDNN/cuBLAS + separate pool / relu kernels.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class _DropState:
+    """Counter-based dropout stream: masks are a pure function of (seed, step, layer)."""
+
+    def __init__(self, seed: int = 1234):
+        self.seed, self.step = seed, 0
+
+    def next(self) -> int:
+        self.step += 1
+        return self.step
+
+
+class Net(nn.Module):
+    """2 conv + 2 fc MNIST CNN with dropout (reference DP.py:77-95). 21,840 parameters."""
+
+    def __init__(self, seed: int = 1234):
+        super().__init__()
+        self.conv1 = nn.Conv2d(1, 10, kernel_size=5)
+        self.conv2 = nn.Conv2d(10, 20, kernel_size=5)
+        self.conv2_drop = nn.Dropout2d()
+        self.fc1 = nn.Linear(320, 50)
+        self.fc2 = nn.Linear(50, 10)
+        self._drop = _DropState(seed)
+
+    def features(self, x: torch.Tensor) -> torch.Tensor:
+        x = ops.conv5_pool_relu(x, self.conv1.weight, self.conv1.bias)
+        mask = None
+        if self.training and self.conv2_drop.p > 0:
+            mask = ops.channel_dropout_mask(x.shape[0], 20, self.conv2_drop.p, x, self._drop.seed,
+                                            self._drop.next() * 1_000_003)
+        x = ops.conv5_pool_relu(x, self.conv2.weight, self.conv2.bias, mask)
+        return x.reshape(-1, 320)
+
+    def logits(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.features(x)
+        x = ops.linear_f32(x, self.fc1.weight, self.fc1.bias, relu=True)
+        x = ops.dropout(x, 0.5, self.training, self._drop.seed, self._drop.next() * 1_000_003 + 7)
+        return ops.linear_f32(x, self.fc2.weight, self.fc2.bias)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.log_softmax(self.logits(x))
+
+
+class Net1(nn.Module):
+    """Model-parallel stage 0: the two conv blocks, no dropout (reference MP.py:76-88)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(1, 10, kernel_size=5)
+        self.conv2 = nn.Conv2d(10, 20, kernel_size=5)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = ops.conv5_pool_relu(x, self.conv1.weight, self.conv1.bias)
+        x = ops.conv5_pool_relu(x, self.conv2.weight, self.conv2.bias)
+        return x.reshape(-1, 320)
+
+
+class Net2(nn.Module):
+    """Model-parallel stage 1: the two FC layers + log-softmax (reference MP.py:90-100)."""
+
+    def __init__(self):
+        super().__init__()
+        self.fc1 = nn.Linear(320, 50)
+        self.fc2 = nn.Linear(50, 10)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = ops.linear_f32(x, self.fc1.weight, self.fc1.bias, relu=True)
+        x = ops.linear_f32(x, self.fc2.weight, self.fc2.bias)
+        return ops.log_softmax(x)
+
+
+def nll_loss(log_probs: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """``F.nll_loss`` equivalent used by both reference loops (DP.py:152, MP.py:160)."""
+    return ops.nll_loss(log_probs, target)
+
+
+def mnist_stages():
+    """Layer list for the generic pipeline partitioner (2 stages = the reference split)."""
+    return [Net1(), Net2()]

@@ -1,0 +1,102 @@
+"""Convolution and Linear on the implicit-GEMM MFMA kernels.
+
+Layouts are the kernels' own: activations NHWC bf16, filters ``[K, R, S, C]`` (KRSC).
+Master weights stay fp32; a bf16 shadow (written by the fused optimizer) is what the
+GEMMs read.  Gradients of the weights are produced in fp32 by the wgrad kernel
+(fp32 atomics over the pixel split), so no bf16 rounding ever enters the gradient
+all-reduce.  A Linear layer is the 1x1 / H=W=1 case of the same kernels.
+
+Replaces the cuDNN / cuBLAS calls behind ``nn.Conv2d`` / ``nn.Linear`` in the
+reference (multinode-DP/multinodeDP.py:82-86).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _ext
+from . import sink as _sink
+
+
+def _lp(weight: torch.Tensor, weight_lp: Optional[torch.Tensor]) -> torch.Tensor:
+    """bf16 copy of a master weight: the optimizer-maintained shadow when present."""
+    if weight_lp is not None:
+        return weight_lp
+    C = _ext.load()
+    out = torch.empty(weight.shape, dtype=torch.bfloat16, device=weight.device)
+    C.cast_f32_to_bf16(weight.detach().contiguous(), out)
+    return out
+
+
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, weight_lp, bias, stride, pad, want_stats, act, wshape):
+        C = _ext.load()
+        w = _lp(weight, weight_lp).view(wshape)   # KRSC view (a Linear weight [out,in] is K,1,1,C)
+        outs = C.conv_fprop(x, w, bias, stride, pad, act, want_stats)
+        ctx.save_for_backward(x, w)
+        ctx.weight = weight
+        ctx.bias = bias
+        ctx.geom = (stride, pad, act)
+        if want_stats:
+            ctx.mark_non_differentiable(outs[1])
+            return outs[0], outs[1]
+        return outs[0], None
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        C = _ext.load()
+        x, w = ctx.saved_tensors
+        stride, pad, act = ctx.geom
+        assert act == 0, "fused activation epilogues are forward-only"
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = C.conv_dgrad(dy, C.transpose_filter(w), x.shape[1], x.shape[2], stride, pad)
+        weight = ctx.weight
+        if weight.requires_grad:
+            tgt = _sink.target(weight)
+            if tgt is not None:
+                C.conv_wgrad(x, dy, tgt.view(w.shape), stride, pad)  # accumulate straight into the flat grad buffer
+                _sink.ready(weight)
+            else:
+                dw = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)
+                C.conv_wgrad(x, dy, dw.view(w.shape), stride, pad)
+        bias = ctx.bias
+        if bias is not None and bias.requires_grad:
+            tgt = _sink.target(bias)
+            if tgt is not None:
+                C.colsum(dy, tgt)
+                _sink.ready(bias)
+            else:
+                db = torch.zeros(bias.shape, dtype=torch.float32, device=bias.device)
+                C.colsum(dy, db)
+        return dx, dw, None, db, None, None, None, None, None
+
+
+def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, weight_lp: Optional[torch.Tensor] = None,
+                bias: Optional[torch.Tensor] = None, stride: int = 1, padding: int = 0, want_stats: bool = False):
+    """``x [N,H,W,C]`` * ``weight [K,R,S,C]`` -> ``y [N,Ho,Wo,K]``.
+
+    Returns ``(y, stats)``; ``stats`` holds per-channel (sum, sumsq) partials of ``y``
+    from the GEMM epilogue when ``want_stats`` (GPU only), else None.
+    """
+    if _ext.use_hip(x):
+        return _ConvFn.apply(x, weight, weight_lp, bias, stride, padding, want_stats, 0, tuple(weight.shape))
+    y = F.conv2d(x.permute(0, 3, 1, 2), weight.to(x.dtype).permute(0, 3, 1, 2),
+                 None if bias is None else bias.to(x.dtype), stride=stride, padding=padding)
+    return y.permute(0, 2, 3, 1).contiguous(), None
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, weight_lp: Optional[torch.Tensor] = None,
+           bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``y = x @ weight^T + bias`` with ``weight [out, in]``; any leading dims on ``x``."""
+    if _ext.use_hip(x):
+        lead = x.shape[:-1]
+        cin, cout = weight.shape[1], weight.shape[0]
+        x4 = x.reshape(-1, 1, 1, cin)
+        y, _ = _ConvFn.apply(x4, weight, weight_lp, bias, 1, 0, False, 0, (cout, 1, 1, cin))
+        return y.reshape(*lead, cout)
+    return F.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))

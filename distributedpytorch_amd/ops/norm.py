@@ -1,0 +1,103 @@
+"""BatchNorm (NHWC, fused with ReLU and the residual add) and LayerNorm.
+
+GPU path: the per-channel statistics normally arrive from the producing
+convolution's epilogue (``conv2d_nhwc(..., want_stats=True)``), a tiny finalize
+kernel turns them into per-channel scale/shift, and ONE streaming kernel applies
+``relu(x*scale + shift + residual)``.  Backward is two streaming passes (reduce,
+apply) with the ReLU mask and residual gradient folded in.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _ext
+from . import sink as _sink
+
+
+def _grad_out(param, value):
+    """Route a small fp32 parameter gradient: into the sink when present, else return it."""
+    tgt = _sink.target(param)
+    if tgt is not None:
+        tgt.add_(value.view(tgt.shape))
+        _sink.ready(param)
+        return None
+    return value
+
+
+class _BNTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps):
+        C = _ext.load()
+        P = x.numel() // x.shape[-1]
+        if stats is None:
+            stats = C.bn_stats(x)
+        mean, invstd, scale, shift = C.bn_finalize(stats, P, gamma.detach(), beta.detach(), running_mean, running_var,
+                                                   momentum, eps)
+        y = C.bn_apply(x, residual, scale, shift, relu)
+        ctx.save_for_backward(x, y if relu else x, mean, invstd)
+        ctx.gamma, ctx.beta = gamma, beta
+        ctx.relu, ctx.has_res = relu, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        C = _ext.load()
+        x, y, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        want_res = ctx.has_res and ctx.needs_input_grad[6]
+        dx, dres, dgamma, dbeta = C.bn_backward(dy, y, x, ctx.gamma.detach(), mean, invstd, ctx.relu, want_res)
+        dg = _grad_out(ctx.gamma, dgamma) if ctx.gamma.requires_grad else None
+        db = _grad_out(ctx.beta, dbeta) if ctx.beta.requires_grad else None
+        return dx, None, dg, db, None, None, (dres if want_res else None), None, None, None
+
+
+def batch_norm_nhwc(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                    running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor],
+                    training: bool = True, momentum: float = 0.1, eps: float = 1e-5, relu: bool = False,
+                    residual: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``relu?(BN(x) + residual?)`` over the last (channel) axis of an NHWC tensor."""
+    if _ext.use_hip(x):
+        C = _ext.load()
+        if training:
+            return _BNTrainFn.apply(x, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps)
+        # inference: fold running stats into scale/shift (cold path), apply with the same streaming kernel
+        scale = (gamma.detach() * torch.rsqrt(running_var + eps)).float().contiguous()
+        shift = (beta.detach() - running_mean * scale).float().contiguous()
+        return C.bn_apply(x, residual, scale, shift, relu)
+    xc = x.permute(0, 3, 1, 2) if x.dim() == 4 else x
+    y = F.batch_norm(xc.float(), running_mean, running_var, gamma, beta, training, momentum, eps).to(x.dtype)
+    if x.dim() == 4:
+        y = y.permute(0, 2, 3, 1)
+    if residual is not None:
+        y = y + residual
+    if relu:
+        y = F.relu(y)
+    return y.contiguous()
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        C = _ext.load()
+        y, mean, rstd = C.layernorm_fwd(x, gamma.detach(), beta.detach(), eps)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.gamma, ctx.beta = gamma, beta
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        C = _ext.load()
+        x, mean, rstd = ctx.saved_tensors
+        dx, dg, db = C.layernorm_bwd(dy.contiguous(), x, ctx.gamma.detach(), mean, rstd)
+        dg = _grad_out(ctx.gamma, dg) if ctx.gamma.requires_grad else None
+        db = _grad_out(ctx.beta, db) if ctx.beta.requires_grad else None
+        return dx, dg, db, None
+
+
+def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    if _ext.use_hip(x):
+        return _LayerNormFn.apply(x.contiguous(), gamma, beta, eps)
+    return F.layer_norm(x.float(), (x.shape[-1],), gamma, beta, eps).to(x.dtype)

@@ -1,0 +1,139 @@
+"""Fused optimizers over ``FlatParams`` buffers.
+
+``FusedSGD`` is one kernel launch per parameter group per step:
+
+    g' = g * grad_scale + wd * p ;  m = mu * m + g' ;  p -= lr * m ;
+    p_bf16 = bf16(p) ;  g = 0
+
+It absorbs the reference's ``param.grad /= world_size`` (multinode-DP/multinodeDP.py:129,
+via ``grad_scale``), ``optimizer.zero_grad()`` (DP.py:150) and ``optimizer.step()``
+(DP.py:156, SGD lr 0.01 momentum 0.5; MP.py:120,124 lr 0.01 no momentum), and emits
+the bf16 shadow the MFMA kernels read.  ``state_dict`` follows ``torch.optim.SGD``
+(``state[i]['momentum_buffer']``, ``param_groups``) so checkpoints interoperate.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from .parallel.flat import FlatParams
+
+
+def _no_decay(name: str, p: torch.Tensor) -> bool:
+    return p.dim() <= 1  # biases, BN / LN affine
+
+
+class FusedSGD:
+    def __init__(self, flat: FlatParams, lr: float = 0.01, momentum: float = 0.0, weight_decay: float = 0.0,
+                 nesterov: bool = False, no_decay: Optional[Callable[[str, torch.Tensor], bool]] = _no_decay):
+        self.flat = flat
+        self.lr, self.momentum, self.weight_decay, self.nesterov = lr, momentum, weight_decay, nesterov
+        self.grad_scale = 1.0
+        self.momentum_buf = torch.zeros_like(flat.master) if momentum != 0.0 else None
+        self.steps = 0
+        # contiguous runs of the flat buffer sharing the same weight decay -> one launch each
+        self.segments = self._segments(no_decay)
+
+    def _segments(self, no_decay):
+        f = self.flat
+        runs: List[List[float]] = []
+        for pos, idx in enumerate(f.order):
+            start = f.offsets[idx]
+            end = f.offsets[f.order[pos + 1]] if pos + 1 < len(f.order) else f.total
+            wd = 0.0 if (self.weight_decay == 0.0 or (no_decay and no_decay(f.names[idx], f.params[idx]))) else self.weight_decay
+            if runs and runs[-1][2] == wd:
+                runs[-1][1] = end
+            else:
+                runs.append([start, end, wd])
+        return [(int(a), int(b), float(w)) for a, b, w in runs]
+
+    def zero_grad(self) -> None:
+        self.flat.zero_grad()
+
+    @torch.no_grad()
+    def step(self, grad_scale: Optional[float] = None, zero_grad: bool = True) -> None:
+        f = self.flat
+        gs = self.grad_scale if grad_scale is None else grad_scale
+        if f.device.type == "cuda":
+            from .ops import _ext
+            C = _ext.load()
+            for a, b, wd in self.segments:
+                C.sgd_momentum(f.master[a:b], f.grad[a:b], None if self.momentum_buf is None else self.momentum_buf[a:b],
+                               None if f.lp is None else f.lp[a:b], self.lr, self.momentum, wd, gs, zero_grad, self.nesterov)
+        else:
+            for a, b, wd in self.segments:
+                p, g = f.master[a:b], f.grad[a:b]
+                d = g * gs
+                if wd != 0.0:
+                    d = d + wd * p
+                if self.momentum_buf is not None:
+                    m = self.momentum_buf[a:b]
+                    m.mul_(self.momentum).add_(d)
+                    d = d + self.momentum * m if self.nesterov else m
+                p.add_(d, alpha=-self.lr)
+                if zero_grad:
+                    g.zero_()
+        self.steps += 1
+
+    # ---- torch.optim.SGD-compatible (de)serialisation, parameters in registration order ----
+    def state_dict(self) -> Dict:
+        f = self.flat
+        state = {}
+        if self.momentum_buf is not None and self.steps > 0:
+            for i, p in enumerate(f.params):
+                off = f.offsets[i]
+                state[i] = {"momentum_buffer": self.momentum_buf[off:off + p.numel()].view(p.shape).detach().cpu().clone()}
+        group = dict(lr=self.lr, momentum=self.momentum, dampening=0, weight_decay=self.weight_decay,
+                     nesterov=self.nesterov, maximize=False, foreach=None, differentiable=False, fused=None,
+                     params=list(range(len(f.params))))
+        return {"state": state, "param_groups": [group], "steps": self.steps}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        f = self.flat
+        g = sd["param_groups"][0]
+        self.lr, self.momentum = g["lr"], g["momentum"]
+        self.weight_decay, self.nesterov = g.get("weight_decay", 0.0), g.get("nesterov", False)
+        self.steps = sd.get("steps", 1 if sd["state"] else 0)
+        if self.momentum != 0.0 and self.momentum_buf is None:
+            self.momentum_buf = torch.zeros_like(f.master)
+        for i, st in sd["state"].items():
+            i = int(i)
+            p = f.params[i]
+            off = f.offsets[i]
+            self.momentum_buf[off:off + p.numel()].copy_(st["momentum_buffer"].reshape(-1).to(f.device))
+
+
+class FusedAdamW:
+    """AdamW over the flat buffer (used for the GPT-2 configuration when asked)."""
+
+    def __init__(self, flat: FlatParams, lr: float = 3e-4, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.0):
+        self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, lr, betas, eps, weight_decay
+        self.m = torch.zeros_like(flat.master)
+        self.v = torch.zeros_like(flat.master)
+        self.steps = 0
+        self.grad_scale = 1.0
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+    @torch.no_grad()
+    def step(self, grad_scale: Optional[float] = None, zero_grad: bool = True):
+        f = self.flat
+        gs = self.grad_scale if grad_scale is None else grad_scale
+        self.steps += 1
+        b1, b2 = self.betas
+        if f.device.type == "cuda":
+            from .ops import _ext
+            _ext.load().adamw(f.master, f.grad, self.m, self.v, f.lp, self.lr, b1, b2, self.eps, self.weight_decay, gs,
+                              self.steps, zero_grad)
+        else:
+            g = f.grad * gs
+            self.m.mul_(b1).add_(g, alpha=1 - b1)
+            self.v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            f.master.mul_(1 - self.lr * self.weight_decay)
+            mh = self.m / (1 - b1 ** self.steps)
+            vh = self.v / (1 - b2 ** self.steps)
+            f.master.addcdiv_(mh, vh.sqrt().add_(self.eps), value=-self.lr)
+            if zero_grad:
+                f.grad.zero_()

@@ -1,0 +1,146 @@
+"""Data-parallel engine: bucketed gradient all-reduce over RCCL, overlapped with backward.
+
+Semantics are the reference's synchronous SGD (multinode-DP/multinodeDP.py:118-129,155):
+after backward every rank holds the MEAN of the per-rank gradients.  Mechanism is
+MI355X-first instead of the reference's 8 blocking per-tensor all-reduces after
+backward:
+
+* gradients live in one flat fp32 buffer (``FlatParams``) laid out in backward order;
+  a bucket is a contiguous slice of it, so RCCL reduces in place with no pack/unpack;
+* a bucket's all-reduce is launched asynchronously the moment its last gradient has
+  been produced (autograd post-accumulate hooks / the wgrad sink), on RCCL's own HIP
+  stream, while backward of earlier layers keeps the compute stream busy;
+* the ``1 / world_size`` of DP.py:129 is not a kernel: it is folded into the fused
+  optimizer's ``grad_scale``;
+* bucket sizes are chosen for the xGMI mesh (7 point-to-point links per GPU): few,
+  large messages (default 32 MiB) so each link's share dwarfs per-message latency,
+  with a small FIRST bucket so communication starts early; the small CNN's 87 KB of
+  gradients collapse into ONE all-reduce (the reference issues 8).
+* replicas start identical: same seed (as the reference, DP.py:138) AND a broadcast
+  of rank 0's flat master buffer.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import comm as _comm
+from ..ops import sink as _sink
+from .flat import Bucket, FlatParams
+
+
+class DataParallel:
+    def __init__(self, module: nn.Module, comm: Optional[_comm.Communicator] = None, flat: Optional[FlatParams] = None,
+                 bucket_mb: float = 32.0, first_bucket_mb: float = 4.0, broadcast_params: bool = True,
+                 use_sink: bool = True, use_lp: bool = True):
+        self.module = module
+        self.comm = comm if comm is not None else _comm.Communicator()
+        self.flat = flat if flat is not None else FlatParams(module, use_lp=use_lp)
+        self.world_size = self.comm.world_size
+        self.grad_scale = 1.0 / self.world_size
+        self.buckets: List[Bucket] = self.flat.plan_buckets(int(bucket_mb * 2 ** 20), int(first_bucket_mb * 2 ** 20))
+        self._bucket_of: Dict[int, Bucket] = {}
+        self._uses: Dict[int, int] = {}
+        for b in self.buckets:
+            for idx in b.param_indices:
+                p = self.flat.params[idx]
+                self._bucket_of[id(p)] = b
+                self._uses[id(p)] = int(getattr(p, "_dpa_uses", 1))
+        self._remaining: Dict[int, int] = {}
+        self._sync = True
+        self._armed = False
+        self._launched: List[Bucket] = []
+        self.stats = {"allreduce_calls": 0, "allreduce_bytes": 0}
+        for p in self.flat.params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+        if use_sink and self.flat.device.type == "cuda":
+            self.flat.install_sink(self._on_sink_ready)
+        if broadcast_params and self.world_size > 1:
+            self.comm.broadcast(self.flat.master, src=0)
+            self.flat.refresh_lp()
+            for buf in module.buffers():
+                self.comm.broadcast(buf, src=0)
+        self._arm()
+
+    # ------------------------------------------------------------------ forward passthrough
+    def __call__(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def __getattr__(self, name):
+        return getattr(self.__dict__["module"], name)
+
+    # ------------------------------------------------------------------ readiness tracking
+    def _arm(self) -> None:
+        self._remaining = dict(self._uses)
+        for b in self.buckets:
+            b.pending = sum(1 for _ in b.param_indices)
+            b.work = None
+        self._launched = []
+        self._armed = True
+
+    def no_sync(self):
+        """Context manager: accumulate gradients locally (micro-batches) without communicating."""
+        engine = self
+
+        class _NoSync:
+            def __enter__(self):
+                engine._sync = False
+
+            def __exit__(self, *exc):
+                engine._sync = True
+                return False
+        return _NoSync()
+
+    def _mark(self, p: torch.Tensor) -> None:
+        if not self._sync:
+            return
+        if not self._armed:
+            self._arm()
+        pid = id(p)
+        left = self._remaining.get(pid)
+        if left is None or left <= 0:
+            return
+        self._remaining[pid] = left - 1
+        if left - 1 > 0:
+            return
+        b = self._bucket_of[pid]
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def _on_grad(self, p: torch.Tensor) -> None:          # autograd wrote p.grad (in place into the flat view)
+        self._mark(p)
+
+    def _on_sink_ready(self, p: torch.Tensor) -> None:    # a wgrad kernel accumulated straight into the flat buffer
+        self._mark(p)
+
+    def _launch(self, b: Bucket) -> None:
+        view = self.flat.grad[b.start:b.end]
+        b.work = self.comm.all_reduce(view, async_op=True)
+        self._launched.append(b)
+        self.stats["allreduce_calls"] += 1
+        self.stats["allreduce_bytes"] += view.numel() * 4
+
+    # ------------------------------------------------------------------ step boundary
+    def finish(self) -> None:
+        """Call after backward, before the optimizer: launches any bucket that did not
+        complete through hooks (unused parameters) and waits for all reductions.  The
+        wait only orders the compute stream behind RCCL's stream - no host block."""
+        if self._sync:
+            for b in self.buckets:
+                if b.work is None:
+                    self._launch(b)
+            for b in self._launched:
+                b.work.wait()
+        self._armed = False
+
+    def average_gradients(self) -> None:
+        """Reference-shaped API (DP.py:118-129): reduce everything now, blocking, and scale."""
+        self.finish()
+        if self.world_size > 1:
+            self.flat.grad.mul_(self.grad_scale)
+
+    def state_dict(self):
+        return self.module.state_dict()

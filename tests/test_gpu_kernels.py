@@ -1,0 +1,303 @@
+"""T2: every HIP kernel against a plain-PyTorch fp32 reference of the same op.
+
+Random (never zero / symmetric) data, asymmetric operands, odd and ragged shapes.
+bf16 kernels are compared with an fp32 reference computed from the SAME
+bf16-rounded inputs, so the tolerance only has to cover fp32-accumulate + one
+output rounding.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _C():
+    from distributedpytorch_amd.ops import _ext
+    return _ext.load()
+
+
+def _rand_bf16(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(DEV)
+
+
+def _close(got, ref, rtol, atol, what=""):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = (err > tol).sum().item()
+    assert bad == 0, f"{what}: {bad}/{err.numel()} out of tolerance, max err {err.max().item():.4g}, ref max {ref.abs().max().item():.4g}"
+
+
+CONV_CASES = [
+    # N, H, W, C, K, R, stride, pad
+    (2, 14, 14, 64, 128, 1, 1, 0),
+    (2, 14, 14, 64, 64, 3, 1, 1),     # K<=64 path (256x64 tiles)
+    (3, 15, 13, 32, 136, 3, 1, 1),    # odd spatial, K not a tile multiple
+    (2, 16, 16, 128, 256, 3, 2, 1),   # stride 2
+    (2, 16, 16, 256, 512, 1, 2, 0),   # 1x1 stride 2 (downsample)
+    (2, 32, 32, 8, 64, 7, 2, 3),      # stem shape: C=8 (3 padded), 7x7/2
+    (1, 7, 7, 512, 512, 3, 1, 1),     # small M, deep K
+    (5, 1, 1, 320, 56, 1, 1, 0),      # Linear-shaped, ragged rows
+]
+
+
+def _ref_conv(x, w, stride, pad):
+    return F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), stride=stride, padding=pad)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fprop(case):
+    N, H, W, C, K, R, s, p = case
+    x = _rand_bf16(N, H, W, C, seed=1)
+    w = _rand_bf16(K, R, R, C, scale=1.0 / math.sqrt(R * R * C), seed=2)
+    (y,) = _C().conv_fprop(x, w, None, s, p, 0, False)
+    ref = _ref_conv(x, w, s, p).permute(0, 2, 3, 1)
+    assert y.shape == ref.shape
+    _close(y, ref, 1e-2, 2e-2, "fprop")
+
+
+def test_conv_fprop_bias_relu_and_stats():
+    N, H, W, C, K = 4, 9, 9, 64, 192
+    x = _rand_bf16(N, H, W, C, seed=3)
+    w = _rand_bf16(K, 3, 3, C, scale=0.05, seed=4)
+    b = torch.randn(K, device=DEV)
+    (y,) = _C().conv_fprop(x, w, b, 1, 1, 1, False)
+    ref = F.relu(_ref_conv(x, w, 1, 1) + b.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    _close(y, ref, 1e-2, 2e-2, "bias+relu")
+    y2, stats = _C().conv_fprop(x, w, None, 1, 1, 0, True)
+    yf = y2.float().reshape(-1, K)
+    s = stats.sum(0)
+    _close(s[0], yf.sum(0), 1e-3, 5e-2, "stats sum")
+    _close(s[1], (yf * yf).sum(0), 1e-3, 5e-2, "stats sumsq")
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_dgrad(case):
+    N, H, W, C, K, R, s, p = case
+    Ho, Wo = (H + 2 * p - R) // s + 1, (W + 2 * p - R) // s + 1
+    dy = _rand_bf16(N, Ho, Wo, K, seed=5)
+    w = _rand_bf16(K, R, R, C, scale=1.0 / math.sqrt(R * R * K), seed=6)
+    wt = _C().transpose_filter(w)
+    assert torch.equal(wt, w.permute(3, 1, 2, 0).contiguous())
+    dx = _C().conv_dgrad(dy, wt, H, W, s, p)
+    xr = torch.zeros(N, C, H, W, requires_grad=True)
+    yr = F.conv2d(xr, w.float().cpu().permute(0, 3, 1, 2), stride=s, padding=p)
+    yr.backward(dy.float().cpu().permute(0, 3, 1, 2))
+    _close(dx, xr.grad.permute(0, 2, 3, 1), 1e-2, 2e-2, "dgrad")
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_wgrad(case):
+    N, H, W, C, K, R, s, p = case
+    Ho, Wo = (H + 2 * p - R) // s + 1, (W + 2 * p - R) // s + 1
+    x = _rand_bf16(N, H, W, C, seed=7)
+    dy = _rand_bf16(N, Ho, Wo, K, scale=0.1, seed=8)
+    dw = torch.full((K, R, R, C), 0.5, device=DEV)          # accumulates INTO dw
+    _C().conv_wgrad(x, dy, dw, s, p)
+    wr = torch.zeros(K, C, R, R, requires_grad=True)
+    yr = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wr, stride=s, padding=p)
+    yr.backward(dy.float().cpu().permute(0, 3, 1, 2))
+    ref = wr.grad.permute(0, 2, 3, 1) + 0.5
+    _close(dw, ref, 5e-3, 2e-2, "wgrad")
+
+
+def test_conv_wgrad_split_k_large():
+    """Enough pixels to split the reduction over many workgroups (atomics path)."""
+    N, H, W, C, K = 8, 56, 56, 64, 64
+    x = _rand_bf16(N, H, W, C, seed=9)
+    dy = _rand_bf16(N, H, W, K, scale=0.05, seed=10)
+    dw = torch.zeros(K, 1, 1, C, device=DEV)
+    _C().conv_wgrad(x, dy, dw, 1, 0)
+    ref = dy.float().reshape(-1, K).t() @ x.float().reshape(-1, C)
+    _close(dw.view(K, C), ref, 5e-3, 5e-2, "wgrad split-k")
+
+
+def test_colsum():
+    x = _rand_bf16(1000, 1000, seed=11)
+    out = torch.ones(1000, device=DEV)
+    _C().colsum(x, out)
+    _close(out, x.float().sum(0) + 1, 1e-3, 1e-2, "colsum")
+    x = _rand_bf16(300, 4096, seed=12)
+    out = torch.zeros(4096, device=DEV)
+    _C().colsum(x, out)
+    _close(out, x.float().sum(0), 1e-3, 1e-2, "colsum wide")
+
+
+@pytest.mark.parametrize("shape", [(4, 7, 7, 64), (2, 13, 11, 256), (3, 5, 5, 2048), (64, 28, 28, 128)])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
+def test_batchnorm_fwd_bwd(shape, relu, res):
+    from distributedpytorch_amd import ops
+    C = shape[-1]
+    x = (_rand_bf16(*shape, seed=13) * 2 + 0.5).to(torch.bfloat16)
+    r = _rand_bf16(*shape, seed=14) if res else None
+    gamma = (torch.rand(C, device=DEV) + 0.5).requires_grad_()
+    beta = torch.randn(C, device=DEV).requires_grad_()
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    xg = x.clone().requires_grad_()
+    rg = r.clone().requires_grad_() if res else None
+    y = ops.batch_norm_nhwc(xg, gamma, beta, rm, rv, True, 0.1, 1e-5, relu=relu, residual=rg)
+    dy = _rand_bf16(*shape, seed=15)
+    y.backward(dy)
+    # fp32 reference
+    xr = x.float().cpu().requires_grad_()
+    rr = r.float().cpu().requires_grad_() if res else None
+    gr, br = gamma.detach().cpu().requires_grad_(), beta.detach().cpu().requires_grad_()
+    rm2, rv2 = torch.zeros(C), torch.ones(C)
+    yr = F.batch_norm(xr.permute(0, 3, 1, 2), rm2, rv2, gr, br, True, 0.1, 1e-5).permute(0, 2, 3, 1)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    yr.backward(dy.float().cpu())
+    _close(y, yr, 1e-2, 2e-2, "bn y")
+    _close(rm, rm2, 1e-3, 1e-3, "running mean")
+    _close(rv, rv2, 1e-3, 1e-3, "running var")
+    _close(xg.grad, xr.grad, 2e-2, 3e-2, "bn dx")
+    n = x.numel() / C
+    _close(gamma.grad, gr.grad, 1e-2, 2e-2 * math.sqrt(n), "dgamma")
+    _close(beta.grad, br.grad, 1e-2, 2e-2 * math.sqrt(n), "dbeta")
+    if res:
+        _close(rg.grad, rr.grad, 1e-2, 1e-2, "dres")
+
+
+def test_conv_bn_fused_stats_match_unfused():
+    from distributedpytorch_amd import ops
+    x = _rand_bf16(8, 14, 14, 64, seed=16)
+    w = _rand_bf16(128, 3, 3, 64, scale=0.05, seed=17).float()
+    gamma, beta = torch.rand(128, device=DEV) + 0.5, torch.randn(128, device=DEV)
+    y1, st = ops.conv2d_nhwc(x, w, None, None, 1, 1, want_stats=True)
+    a = ops.batch_norm_nhwc(y1, gamma, beta, None, None, True, relu=True, stats=st)
+    b = ops.batch_norm_nhwc(y1, gamma, beta, None, None, True, relu=True, stats=None)
+    _close(a, b, 1e-2, 1e-2, "fused vs unfused stats")
+
+
+def test_maxpool_avgpool():
+    from distributedpytorch_amd import ops
+    x = _rand_bf16(3, 17, 19, 64, seed=18).requires_grad_()
+    y = ops.max_pool_3x3_s2_nhwc(x)
+    dy = _rand_bf16(*y.shape, seed=19)
+    y.backward(dy)
+    xr = x.detach().float().cpu().requires_grad_()
+    yr = F.max_pool2d(xr.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    yr.backward(dy.float().cpu())
+    _close(y, yr, 0, 0, "maxpool")
+    _close(x.grad, xr.grad, 1e-2, 1e-2, "maxpool bwd")
+    x = _rand_bf16(5, 7, 7, 2048, seed=20).requires_grad_()
+    y = ops.global_avg_pool_nhwc(x)
+    y.backward(torch.ones_like(y))
+    _close(y, x.detach().float().mean((1, 2)), 1e-2, 1e-2, "avgpool")
+    _close(x.grad, torch.full_like(x, 1 / 49.0), 1e-2, 1e-3, "avgpool bwd")
+
+
+def test_nchw_to_nhwc_pad():
+    from distributedpytorch_amd import ops
+    x = torch.randn(3, 3, 20, 24, device=DEV)
+    y = ops.to_nhwc(x, 8)
+    assert y.shape == (3, 20, 24, 8) and y.dtype == torch.bfloat16
+    _close(y[..., :3], x.permute(0, 2, 3, 1), 1e-2, 1e-2, "layout")
+    assert float(y[..., 3:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,V,ld,dtype", [(12, 10, 10, torch.float32), (96, 1000, 1000, torch.bfloat16),
+                                          (33, 50257, 50304, torch.bfloat16), (7, 13, 16, torch.bfloat16)])
+def test_softmax_ce(B, V, ld, dtype):
+    from distributedpytorch_amd import ops
+    logits = (torch.randn(B, ld, device=DEV) * 3).to(dtype)
+    t = torch.randint(0, V, (B,), device=DEV)
+    lg = logits.clone().requires_grad_()
+    loss = ops.softmax_cross_entropy(lg, t, V)
+    (loss * 2.0).backward()
+    lr = logits.float().cpu()[:, :V].requires_grad_()
+    ref = F.cross_entropy(lr, t.cpu())
+    (ref * 2.0).backward()
+    _close(loss, ref, 1e-3, 1e-3, "ce loss")
+    _close(lg.grad[:, :V], lr.grad, 2e-2, 1e-5, "ce grad")
+    if ld > V:
+        assert float(lg.grad[:, V:].abs().max()) == 0.0
+
+
+def test_fused_sgd_matches_torch():
+    n = 100003
+    p = torch.randn(n, device=DEV); g = torch.randn(n, device=DEV); m = torch.randn(n, device=DEV)
+    lp = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    p0, g0, m0 = p.clone(), g.clone(), m.clone()
+    _C().sgd_momentum(p, g, m, lp, 0.01, 0.5, 1e-4, 0.125, True, False)
+    d = g0 * 0.125 + 1e-4 * p0
+    mr = 0.5 * m0 + d
+    pr = p0 - 0.01 * mr
+    _close(p, pr, 1e-6, 1e-6, "sgd p")
+    _close(m, mr, 1e-6, 1e-6, "sgd m")
+    _close(lp, pr, 1e-2, 1e-3, "sgd bf16 shadow")
+    assert float(g.abs().max()) == 0.0
+
+
+def test_mnist_ops_match_torch():
+    """Fused conv+pool+relu / linear / log-softmax / nll vs the reference's op chain."""
+    from distributedpytorch_amd import ops
+    torch.manual_seed(0)
+    for B in (12, 96):                      # ragged last batches of the reference configs
+        x = torch.randn(B, 1, 28, 28, device=DEV, requires_grad=True)
+        w1 = (torch.randn(10, 1, 5, 5, device=DEV) * 0.2).requires_grad_(); b1 = torch.randn(10, device=DEV).requires_grad_()
+        w2 = (torch.randn(20, 10, 5, 5, device=DEV) * 0.1).requires_grad_(); b2 = torch.randn(20, device=DEV).requires_grad_()
+        f1 = (torch.randn(50, 320, device=DEV) * 0.05).requires_grad_(); fb1 = torch.randn(50, device=DEV).requires_grad_()
+        f2 = (torch.randn(10, 50, device=DEV) * 0.1).requires_grad_(); fb2 = torch.randn(10, device=DEV).requires_grad_()
+        t = torch.randint(0, 10, (B,), device=DEV)
+        h = ops.conv5_pool_relu(x, w1, b1)
+        h = ops.conv5_pool_relu(h, w2, b2).reshape(-1, 320)
+        h = ops.linear_f32(h, f1, fb1, relu=True)
+        lp = ops.log_softmax(ops.linear_f32(h, f2, fb2))
+        loss = ops.nll_loss(lp, t)
+        loss.backward()
+        params = [x, w1, b1, w2, b2, f1, fb1, f2, fb2]
+        cp = [p.detach().cpu().requires_grad_() for p in params]
+        xr, w1r, b1r, w2r, b2r, f1r, fb1r, f2r, fb2r = cp
+        hr = F.relu(F.max_pool2d(F.conv2d(xr, w1r, b1r), 2))
+        hr = F.relu(F.max_pool2d(F.conv2d(hr, w2r, b2r), 2)).view(-1, 320)
+        hr = F.relu(F.linear(hr, f1r, fb1r))
+        lpr = F.log_softmax(F.linear(hr, f2r, fb2r), dim=1)
+        lossr = F.nll_loss(lpr, t.cpu())
+        lossr.backward()
+        _close(lp, lpr, 1e-4, 1e-4, "log-probs")
+        _close(loss, lossr, 1e-4, 1e-5, "loss")
+        for a, b, name in zip(params, cp, "x w1 b1 w2 b2 f1 fb1 f2 fb2".split()):
+            _close(a.grad, b.grad, 1e-3, 1e-5, "grad " + name)
+
+
+def test_layernorm_gelu_embedding():
+    from distributedpytorch_amd import ops
+    x = _rand_bf16(37, 768, seed=21).requires_grad_()
+    g = (torch.rand(768, device=DEV) + 0.5).requires_grad_(); b = torch.randn(768, device=DEV).requires_grad_()
+    y = ops.layer_norm(x, g, b)
+    dy = _rand_bf16(37, 768, seed=22)
+    y.backward(dy)
+    xr = x.detach().float().cpu().requires_grad_(); gr = g.detach().cpu().requires_grad_(); br = b.detach().cpu().requires_grad_()
+    yr = F.layer_norm(xr, (768,), gr, br)
+    yr.backward(dy.float().cpu())
+    _close(y, yr, 1e-2, 2e-2, "ln")
+    _close(x.grad, xr.grad, 2e-2, 2e-2, "ln dx")
+    _close(g.grad, gr.grad, 1e-2, 5e-2, "ln dg")
+    _close(b.grad, br.grad, 1e-2, 5e-2, "ln db")
+    x = _rand_bf16(1000, 3072 // 8 * 8 + 8, seed=23).requires_grad_()
+    y = ops.gelu(x); y.backward(torch.ones_like(y))
+    xr = x.detach().float().cpu().requires_grad_()
+    yr = F.gelu(xr, approximate="tanh"); yr.backward(torch.ones_like(yr))
+    _close(y, yr, 1e-2, 1e-2, "gelu")
+    _close(x.grad, xr.grad, 1e-2, 1e-2, "gelu grad")
+    V, T, Cc = 500, 32, 128
+    wte = torch.randn(V, Cc, device=DEV).requires_grad_(); wpe = torch.randn(64, Cc, device=DEV).requires_grad_()
+    tok = torch.randint(0, V, (3, T), device=DEV)
+    e = ops.embedding(tok, wte, wpe)
+    de = _rand_bf16(3, T, Cc, seed=24)
+    e.backward(de)
+    wter = wte.detach().cpu().to(torch.bfloat16).float().requires_grad_(); wper = wpe.detach().cpu().to(torch.bfloat16).float().requires_grad_()
+    er = wter[tok.cpu()] + wper[:T].unsqueeze(0)
+    er.backward(de.float().cpu())
+    _close(e, er, 1e-2, 1e-2, "embedding")
+    _close(wte.grad, wter.grad, 1e-3, 1e-3, "dwte")
+    _close(wpe.grad, wper.grad, 1e-3, 1e-3, "dwpe")
