@@ -77,7 +77,7 @@ def build(verbose: bool = True, jobs: int = 8) -> Path:
     common = ["-O3", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", f"-D_GLIBCXX_USE_CXX11_ABI={abi}"]
     if have_attention:
         common.append("-DDPA_HAVE_ATTENTION=1")
-    kernel_flags = common + [f"--offload-arch={ARCH}", "-ffast-math", "-fno-gpu-rdc", "-Wno-unused-result"]
+    kernel_flags = common + [f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wno-unused-result"]
     bind_flags = common + inc + [f"-DTORCH_EXTENSION_NAME={MODULE}", "-DTORCH_API_INCLUDE_EXTENSION_H",
                                  "-Wno-deprecated-declarations", "-I/opt/rocm/include"]
     tasks = []

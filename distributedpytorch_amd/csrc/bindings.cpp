@@ -3,8 +3,8 @@
 // BEFORE launching (an out-of-bounds kernel access can reset the whole GPU), and
 // launches on PyTorch's current HIP stream so ordering with autograd is implicit.
 #include <torch/extension.h>
-#include <c10/hip/HIPStream.h>
-#include <c10/hip/HIPGuard.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include "kernels.h"
 
@@ -12,7 +12,7 @@ namespace {
 
 using torch::Tensor;
 
-inline hipStream_t cur_stream() { return c10::hip::getCurrentHIPStream().stream(); }
+inline hipStream_t cur_stream() { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(); }
 
 #define CHECK_DEV(t) TORCH_CHECK((t).is_cuda(), #t " must be a GPU tensor")
 #define CHECK_CONTIG(t) TORCH_CHECK((t).is_contiguous(), #t " must be contiguous")
@@ -22,7 +22,7 @@ inline hipStream_t cur_stream() { return c10::hip::getCurrentHIPStream().stream(
 #define CHECK_I64(t) do { CHECK_DEV(t); CHECK_CONTIG(t); TORCH_CHECK((t).scalar_type() == at::kLong, #t " must be int64"); } while (0)
 
 struct Guard {
-    c10::hip::HIPGuard g;
+    c10::hip::HIPGuardMasqueradingAsCUDA g;
     explicit Guard(const Tensor& t) : g(t.device()) {}
 };
 

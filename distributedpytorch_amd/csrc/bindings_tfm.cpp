@@ -1,13 +1,13 @@
 // Bindings for the transformer (GPT-2) kernels: LayerNorm, embedding, causal attention.
 #include <torch/extension.h>
-#include <c10/hip/HIPStream.h>
-#include <c10/hip/HIPGuard.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include "kernels.h"
 
 namespace {
 using torch::Tensor;
-inline hipStream_t cur_stream() { return c10::hip::getCurrentHIPStream().stream(); }
+inline hipStream_t cur_stream() { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(); }
 
 #define CHECK_DEV(t) TORCH_CHECK((t).is_cuda(), #t " must be a GPU tensor")
 #define CHECK_CONTIG(t) TORCH_CHECK((t).is_contiguous(), #t " must be contiguous")
@@ -21,7 +21,7 @@ std::vector<Tensor> layernorm_fwd(const Tensor& x, const Tensor& g, const Tensor
     CHECK_BF16(x); CHECK_F32(g); CHECK_F32(b);
     const int64_t C = x.size(-1), rows = x.numel() / C;
     TORCH_CHECK(C % 8 == 0 && C <= 2048 && g.numel() == C && b.numel() == C, "layernorm: C must be a multiple of 8, <= 2048");
-    c10::hip::HIPGuard guard(x.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     auto fopt = x.options().dtype(at::kFloat);
     Tensor y = torch::empty_like(x), mean = torch::empty({rows}, fopt), rstd = torch::empty({rows}, fopt);
     dpa::layernorm_fwd(x.data_ptr(), g.data_ptr<float>(), b.data_ptr<float>(), y.data_ptr(), mean.data_ptr<float>(),
@@ -35,7 +35,7 @@ std::vector<Tensor> layernorm_bwd(const Tensor& dy, const Tensor& x, const Tenso
     const int64_t C = x.size(-1), rows = x.numel() / C;
     TORCH_CHECK(dy.numel() == x.numel() && C % 8 == 0 && C <= 2048 && g.numel() == C && mean.numel() == rows && rstd.numel() == rows,
                 "layernorm_bwd: shapes");
-    c10::hip::HIPGuard guard(x.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     auto fopt = x.options().dtype(at::kFloat);
     const int pr = dpa::layernorm_partial_rows(rows);
     Tensor dx = torch::empty_like(x), part = torch::empty({2, pr, C}, fopt), dgb = torch::empty({2, C}, fopt);
@@ -55,7 +55,7 @@ Tensor embedding_fwd(const Tensor& tok, const Tensor& wte, const Tensor& wpe) {
     const int64_t B = tok.size(0), T = tok.size(1), C = wte.size(1);
     TORCH_CHECK(C % 8 == 0 && T <= wpe.size(0), "embedding: C % 8, T <= positions");
     // token range is validated on the host only in debug runs (it needs a sync); the kernel clamps.
-    c10::hip::HIPGuard guard(wte.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(wte.device());
     Tensor y = torch::empty({B, T, C}, wte.options());
     dpa::embedding_fwd(tok.data_ptr<int64_t>(), wte.data_ptr(), wpe.data_ptr(), y.data_ptr(), B, T, C, wte.size(0), cur_stream());
     return y;
@@ -66,7 +66,7 @@ void embedding_bwd(const Tensor& tok, const Tensor& dy, Tensor& dwte, Tensor& dw
     CHECK_I64(tok); CHECK_BF16(dy); CHECK_F32(dwte); CHECK_F32(dwpe);
     const int64_t B = tok.size(0), T = tok.size(1), C = dy.size(-1);
     TORCH_CHECK(dy.numel() == B * T * C && dwte.size(1) == C && dwpe.size(1) == C && T <= dwpe.size(0) && C % 8 == 0, "embedding_bwd: shapes");
-    c10::hip::HIPGuard guard(dy.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dy.device());
     dpa::embedding_bwd(tok.data_ptr<int64_t>(), dy.data_ptr(), dwte.data_ptr<float>(), dwpe.data_ptr<float>(), B, T, C, dwte.size(0), cur_stream());
 }
 
@@ -77,7 +77,7 @@ std::vector<Tensor> attention_fwd(const Tensor& qkv) {
     TORCH_CHECK(qkv.dim() == 5 && qkv.size(2) == 3 && qkv.size(4) == 64, "attention: qkv must be [B,T,3,H,64]");
     const int64_t B = qkv.size(0), T = qkv.size(1), H = qkv.size(3), D = qkv.size(4);
     TORCH_CHECK(T % 64 == 0, "attention: T must be a multiple of 64");
-    c10::hip::HIPGuard guard(qkv.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(qkv.device());
     Tensor out = torch::empty({B, T, H, D}, qkv.options());
     Tensor lse = torch::empty({B, H, T}, qkv.options().dtype(at::kFloat));
     dpa::attention_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr<float>(), B, T, H, D, cur_stream());
@@ -89,7 +89,7 @@ Tensor attention_bwd(const Tensor& qkv, const Tensor& out, const Tensor& dout, c
     TORCH_CHECK(qkv.dim() == 5 && qkv.size(2) == 3 && qkv.size(4) == 64, "attention_bwd: qkv must be [B,T,3,H,64]");
     const int64_t B = qkv.size(0), T = qkv.size(1), H = qkv.size(3), D = qkv.size(4);
     TORCH_CHECK(T % 64 == 0 && out.numel() == B * T * H * D && dout.numel() == out.numel() && lse.numel() == B * H * T, "attention_bwd: shapes");
-    c10::hip::HIPGuard guard(qkv.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(qkv.device());
     Tensor dqkv = torch::empty_like(qkv);
     Tensor delta = torch::empty({B, H, T}, lse.options());
     dpa::attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr<float>(), dqkv.data_ptr(),

@@ -34,9 +34,12 @@ template <> struct RowIO<float> {
     __device__ static void store1(float* p, float v) { *p = v; }
 };
 
+constexpr float NEG_BIG = -1.0e30f;
+
 __device__ __forceinline__ void online_merge(float& m, float& s, float m2, float s2) {
+    // m starts at the finite sentinel NEG_BIG (never -inf): exp(NEG_BIG - x) == 0 and
+    // NEG_BIG - NEG_BIG == 0, so empty lanes merge without producing inf - inf = NaN.
     const float mn = fmaxf(m, m2);
-    if (mn == -INFINITY) { m = mn; s = 0.f; return; }
     s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
     m = mn;
 }
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logit
                                                      int V, long ld, float scale, int64_t ignore_index, int vec_ok) {
     const long row = blockIdx.x;
     const T* x = logits + row * ld;
-    float m = -INFINITY, s = 0.f;
+    float m = NEG_BIG, s = 0.f;
     if (vec_ok) {
         const int nv = V / 8;
         for (int i = threadIdx.x; i < nv; i += 256) {

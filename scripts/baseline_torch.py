@@ -76,8 +76,10 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(a.warmup):
+    for i in range(a.warmup):
         step()
+        torch.cuda.synchronize()
+        print(f"[baseline] warmup step {i} done", flush=True)   # MIOpen's first-call search is slow; keep the log alive
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
