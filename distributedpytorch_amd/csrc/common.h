@@ -11,6 +11,8 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) short short4v;
 typedef __attribute__((ext_vector_type(4))) float floatx4;
 typedef __attribute__((ext_vector_type(16))) float floatx16;
+// native 16-byte register vector: unlike HIP's uint4 struct it stays in VGPRs through selects
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 constexpr int kWave = 64;
 

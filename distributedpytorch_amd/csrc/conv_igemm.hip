@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c
     const int chunk = tid & 3;
     const int lrow = tid >> 2;  // 0..63
     int hi0[XR], wi0[XR];
-    long nb[XR];
+    int nb[XR];
     bool rvalid[XR];
     const int HoWo = a.Ho * a.Wo;
 #pragma unroll
@@ -75,57 +75,67 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c
         int n = (int)(mm / HoWo);
         int rem = (int)(mm - (long)n * HoWo);
         int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-        nb[i] = (long)n * a.H * a.W;
+        nb[i] = n * a.H * a.W;
         if (MODE == 0) { hi0[i] = ho * a.stride - a.pad; wi0[i] = wo * a.stride - a.pad; }
         else           { hi0[i] = ho + a.pad;            wi0[i] = wo + a.pad; }
     }
     int kr = 0, ks = 0, kc = chunk * 8;  // (r, s, c) of this thread's chunk
     while (kc >= a.C) { kc -= a.C; if (++ks == a.S) { ks = 0; ++kr; } }
 
-    uint4 xreg[XR], wreg[WR];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    u32x4 xreg[XR], wreg[WR];
+    unsigned okmask = 0;   // bit i: x row i valid, bit 8+i: w row i valid (tile in flight)
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-    auto load_tile = [&](int kt) {
-        const bool kok = kr < a.R;
-#pragma unroll
-        for (int i = 0; i < XR; ++i) {
-            int hi, wi;
-            bool ok = rvalid[i] && kok;
-            if (MODE == 0) {
-                hi = hi0[i] + kr; wi = wi0[i] + ks;
-            } else {
-                int th = hi0[i] - kr, tw = wi0[i] - ks;
-                if (a.stride == 1) { hi = th; wi = tw; }
-                else {
-                    ok = ok && th >= 0 && tw >= 0;
-                    hi = th / a.stride; wi = tw / a.stride;
-                    ok = ok && (hi * a.stride == th) && (wi * a.stride == tw);
-                }
-            }
-            ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            xreg[i] = zero4;
-            if (ok) xreg[i] = *(const uint4*)(xg + ((nb[i] + (long)hi * a.W + wi) * a.C + kc));
-        }
-        const int k = kt * BK + chunk * 8;
-#pragma unroll
-        for (int i = 0; i < WR; ++i) {
-            int co = c0 + lrow + i * 64;
-            wreg[i] = zero4;
-            if (co < a.K && k < Kg) wreg[i] = *(const uint4*)(wg + ((long)co * Kg + k));
-        }
-        kc += BK;
-        while (kc >= a.C) { kc -= a.C; if (++ks == a.S) { ks = 0; ++kr; } }
-    };
+    // Branch-free gather: every lane ALWAYS issues its 16-byte loads (an invalid lane reads
+    // the tensor's first bytes, which stay cached) and the value is zeroed by a select when
+    // it is written to LDS - after the MFMAs of the current tile, so the wait on the loads
+    // sits behind the compute.  (A predicated `if (ok) load` makes hipcc wait vmcnt(0) right
+    // behind each load: four serialised HBM round trips per K step.)  Offsets are 32-bit
+    // element indices (host checks numel < 2^31) so the address math is a few VALU ops.
+#define DPA_LOAD_TILE(KT)                                                                        \
+    {                                                                                            \
+        const bool kok = kr < a.R;                                                               \
+        okmask = 0;                                                                              \
+        _Pragma("unroll") for (int i = 0; i < XR; ++i) {                                         \
+            int hi, wi;                                                                          \
+            bool ok = rvalid[i] && kok;                                                          \
+            if (MODE == 0) {                                                                     \
+                hi = hi0[i] + kr; wi = wi0[i] + ks;                                              \
+            } else {                                                                             \
+                const int th = hi0[i] - kr, tw = wi0[i] - ks;                                    \
+                if (a.stride == 1) { hi = th; wi = tw; }                                         \
+                else {                                                                           \
+                    hi = th / a.stride; wi = tw / a.stride;                                      \
+                    ok = ok && th >= 0 && tw >= 0 && (hi * a.stride == th) && (wi * a.stride == tw); \
+                }                                                                                \
+            }                                                                                    \
+            ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;             \
+            const unsigned off = ok ? (unsigned)((nb[i] + hi * a.W + wi) * a.C + kc) : 0u;       \
+            xreg[i] = *(const u32x4*)(xg + off);                                                 \
+            okmask |= (ok ? 1u : 0u) << i;                                                       \
+        }                                                                                        \
+        const int k = (KT) * BK + chunk * 8;                                                     \
+        _Pragma("unroll") for (int i = 0; i < WR; ++i) {                                         \
+            const int co = c0 + lrow + i * 64;                                                   \
+            const bool ok = co < a.K && k < Kg;                                                  \
+            const unsigned off = ok ? (unsigned)(co * Kg + k) : 0u;                              \
+            wreg[i] = *(const u32x4*)(wg + off);                                                 \
+            okmask |= (ok ? 1u : 0u) << (8 + i);                                                 \
+        }                                                                                        \
+        kc += BK;                                                                                \
+        while (kc >= a.C) { kc -= a.C; if (++ks == a.S) { ks = 0; ++kr; } }                      \
+    }
 
     const int wsw = chunk ^ swz4(lrow);  // (row>>2)&3 is the same for lrow + 64*i
-    auto store_tile = [&](int buf) {
-        unsigned char* xs = smem + buf * STAGE_BYTES;
-        unsigned char* ws = xs + BP * BK * 2;
-#pragma unroll
-        for (int i = 0; i < XR; ++i) *(uint4*)(xs + ((lrow + i * 64) * CHUNKS + wsw) * 16) = xreg[i];
-#pragma unroll
-        for (int i = 0; i < WR; ++i) *(uint4*)(ws + ((lrow + i * 64) * CHUNKS + wsw) * 16) = wreg[i];
-    };
+#define DPA_STORE_TILE(BUF)                                                                      \
+    {                                                                                            \
+        unsigned char* xs_ = smem + (BUF) * STAGE_BYTES;                                         \
+        unsigned char* ws_ = xs_ + BP * BK * 2;                                                  \
+        _Pragma("unroll") for (int i = 0; i < XR; ++i)                                           \
+            *(u32x4*)(xs_ + ((lrow + i * 64) * CHUNKS + wsw) * 16) = ((okmask >> i) & 1u) ? xreg[i] : zero4;       \
+        _Pragma("unroll") for (int i = 0; i < WR; ++i)                                           \
+            *(u32x4*)(ws_ + ((lrow + i * 64) * CHUNKS + wsw) * 16) = ((okmask >> (8 + i)) & 1u) ? wreg[i] : zero4; \
+    }
 
     floatx4 acc[4][4];
 #pragma unroll
@@ -137,12 +147,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c
     const int frow = lane & 15;
     const int fsw = (lane >> 4) ^ swz4(frow);
 
-    load_tile(0);
-    store_tile(0);
+    DPA_LOAD_TILE(0)
+    DPA_STORE_TILE(0)
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (kt + 1 < nk) DPA_LOAD_TILE(kt + 1)
         const unsigned char* xs = smem + cur * STAGE_BYTES;
         const unsigned char* ws = xs + BP * BK * 2;
         bf16x8 af[4], bfr[4];
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+        if (kt + 1 < nk) DPA_STORE_TILE(cur ^ 1)
         __syncthreads();
         cur ^= 1;
     }
@@ -222,6 +232,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c
         }
     }
 }
+
+#undef DPA_LOAD_TILE
+#undef DPA_STORE_TILE
 
 template <int WP, int WC>
 void launch(const ConvArgs& a, hipStream_t st) {

@@ -94,25 +94,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int tiles_
         pn[i] = n; pho[i] = rem / a.Wo; pwo[i] = rem - pho[i] * a.Wo;
     }
 
-    uint4 areg[A_LD], breg[B_LD];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    u32x4 areg[A_LD], breg[B_LD];
+    bool aok[A_LD], bok[B_LD];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
+    // Branch-free loads (see conv_igemm.hip): always load, select zero afterwards.
     auto load_tile = [&](int st) {
         const long pb = p_begin + (long)st * BKP;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             const long p = pb + a_row0 + i * A_RSTEP;
-            areg[i] = zero4;
-            if (a_cok && p < p_end) areg[i] = *(const uint4*)(dyg + p * a.K + k0 + a_ch * 8);
+            const bool ok = a_cok && p < p_end;
+            const long off = ok ? (p * a.K + k0 + a_ch * 8) : 0;
+            areg[i] = *(const u32x4*)(dyg + off);
+            aok[i] = ok;
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
             const long p = pb + b_row0 + i * B_RSTEP;
             const int hi = pho[i] * a.stride - a.pad + fr;
             const int wi = pwo[i] * a.stride - a.pad + fs;
-            breg[i] = zero4;
-            if (b_cok && p < p_end && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
-                breg[i] = *(const uint4*)(xg + ((((long)pn[i] * a.H + hi) * a.W + wi) * a.C + fc));
+            const bool ok = b_cok && p < p_end && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            const long off = ok ? ((((long)pn[i] * a.H + hi) * a.W + wi) * a.C + fc) : 0;
+            breg[i] = *(const u32x4*)(xg + off);
+            bok[i] = ok;
             // advance this row's pixel by BKP
             pwo[i] += BKP;
             while (pwo[i] >= a.Wo) { pwo[i] -= a.Wo; if (++pho[i] == a.Ho) { pho[i] = 0; ++pn[i]; } }
@@ -127,13 +132,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int tiles_
         for (int i = 0; i < A_LD; ++i) {
             const int row = a_row0 + i * A_RSTEP;
             const int ch = (((a_ch >> 2) ^ swz_key<BM * 2>(row)) << 2) | (a_ch & 3);
-            *(uint4*)(as + row * (BM * 2) + ch * 16) = areg[i];
+            *(u32x4*)(as + row * (BM * 2) + ch * 16) = aok[i] ? areg[i] : zero4;
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
             const int row = b_row0 + i * B_RSTEP;
             const int ch = (((b_ch >> 2) ^ swz_key<BN * 2>(row)) << 2) | (b_ch & 3);
-            *(uint4*)(bs + row * (BN * 2) + ch * 16) = breg[i];
+            *(u32x4*)(bs + row * (BN * 2) + ch * 16) = bok[i] ? breg[i] : zero4;
         }
     };
 
