@@ -53,7 +53,20 @@ class ResNet50(nn.Module):
         return self.fc(torch.flatten(F.adaptive_avg_pool2d(x, 1), 1))
 
 
+def _heartbeat():
+    """MIOpen's first-call kernel search can run for minutes without output."""
+    import threading
+    t0 = time.time()
+
+    def beat():
+        while True:
+            time.sleep(30)
+            print(f"[baseline] alive, {time.time() - t0:.0f}s (MIOpen search / warmup)", flush=True)
+    threading.Thread(target=beat, daemon=True).start()
+
+
 def main():
+    _heartbeat()
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)

@@ -1,0 +1,93 @@
+#!/usr/bin/env python
+"""Per-layer micro-benchmark of the implicit-GEMM conv kernels on the ResNet-50 shapes
+(batch 256): time, TFLOP/s and effective GB/s of fprop / dgrad / wgrad per distinct shape.
+Random data (never zeros: zero operands raise the clock and flatter the number)."""
+import argparse
+import json
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from distributedpytorch_amd.ops import _ext  # noqa: E402
+
+# (name, H, C, K, R, stride, pad, count)  -- distinct ResNet-50 conv shapes at 224x224
+SHAPES = [
+    ("stem7x7", 224, 8, 64, 7, 2, 3, 1),
+    ("l1.c1 1x1 64-64", 56, 64, 64, 1, 1, 0, 1),
+    ("l1.c2 3x3 64-64", 56, 64, 64, 3, 1, 1, 3),
+    ("l1.c3 1x1 64-256", 56, 64, 256, 1, 1, 0, 4),
+    ("l1.c1 1x1 256-64", 56, 256, 64, 1, 1, 0, 2),
+    ("l2.c1 1x1 256-128", 56, 256, 128, 1, 1, 0, 1),
+    ("l2.c2 3x3s2 128", 56, 128, 128, 3, 2, 1, 1),
+    ("l2.ds 1x1s2 256-512", 56, 256, 512, 1, 2, 0, 1),
+    ("l2.c3 1x1 128-512", 28, 128, 512, 1, 1, 0, 4),
+    ("l2.c1 1x1 512-128", 28, 512, 128, 1, 1, 0, 3),
+    ("l2.c2 3x3 128", 28, 128, 128, 3, 1, 1, 3),
+    ("l3.c1 1x1 512-256", 28, 512, 256, 1, 1, 0, 1),
+    ("l3.c2 3x3s2 256", 28, 256, 256, 3, 2, 1, 1),
+    ("l3.ds 1x1s2 512-1024", 28, 512, 1024, 1, 2, 0, 1),
+    ("l3.c3 1x1 256-1024", 14, 256, 1024, 1, 1, 0, 6),
+    ("l3.c1 1x1 1024-256", 14, 1024, 256, 1, 1, 0, 5),
+    ("l3.c2 3x3 256", 14, 256, 256, 3, 1, 1, 5),
+    ("l4.c1 1x1 1024-512", 14, 1024, 512, 1, 1, 0, 1),
+    ("l4.c2 3x3s2 512", 14, 512, 512, 3, 2, 1, 1),
+    ("l4.ds 1x1s2 1024-2048", 14, 1024, 2048, 1, 2, 0, 1),
+    ("l4.c3 1x1 512-2048", 7, 512, 2048, 1, 1, 0, 3),
+    ("l4.c1 1x1 2048-512", 7, 2048, 512, 1, 1, 0, 2),
+    ("l4.c2 3x3 512", 7, 512, 512, 3, 1, 1, 2),
+]
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    C = _ext.load()
+    dev = "cuda"
+    N = a.batch
+    tot = {"fprop": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+    rows = []
+    print(f"{'layer':24s} {'x':>3s} | {'fprop us':>9s} {'TF/s':>6s} {'GB/s':>6s} | {'dgrad us':>9s} {'TF/s':>6s} | {'wgrad us':>9s} {'TF/s':>6s}")
+    for name, H, Cin, K, R, s, p, cnt in SHAPES:
+        if a.only and a.only not in name:
+            continue
+        Ho = (H + 2 * p - R) // s + 1
+        x = torch.randn(N, H, H, Cin, device=dev).to(torch.bfloat16)
+        w = (torch.randn(K, R, R, Cin, device=dev) * 0.05).to(torch.bfloat16)
+        dy = torch.randn(N, Ho, Ho, K, device=dev).to(torch.bfloat16)
+        wt = C.transpose_filter(w)
+        dw = torch.zeros(K, R, R, Cin, device=dev)
+        flops = 2.0 * N * Ho * Ho * K * R * R * Cin
+        byts = 2.0 * (x.numel() + dy.numel() + w.numel())
+        tf = timeit(lambda: C.conv_fprop(x, w, None, s, p, 0, True), a.iters)
+        td = timeit(lambda: C.conv_dgrad(dy, wt, H, H, s, p), a.iters) if name != "stem7x7" else 0.0
+        tw = timeit(lambda: C.conv_wgrad(x, dy, dw, s, p), a.iters)
+        rows.append(dict(name=name, count=cnt, fprop_us=tf, dgrad_us=td, wgrad_us=tw, gflop=flops / 1e9))
+        tot["fprop"] += tf * cnt; tot["dgrad"] += td * cnt; tot["wgrad"] += tw * cnt
+        print(f"{name:24s} {cnt:3d} | {tf:9.1f} {flops / tf / 1e6:6.0f} {byts / tf / 1e3:6.0f} | {td:9.1f} "
+              f"{(flops / td / 1e6 if td else 0):6.0f} | {tw:9.1f} {flops / tw / 1e6:6.0f}", flush=True)
+    print("per-step totals (ms):", {k: round(v / 1e3, 2) for k, v in tot.items()}, "sum", round(sum(tot.values()) / 1e3, 2))
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump({"rows": rows, "totals_ms": {k: v / 1e3 for k, v in tot.items()}}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
