@@ -267,15 +267,18 @@ def build_grid(world: Communicator, dp: int, pp: int):
     """DP x PP process grid.  Rank layout: ``rank = replica * pp + stage`` so the
     stages of one pipeline replica are adjacent GPUs.  Returns
     ``(pp_comm, dp_comm, replica, stage)``; ``pp_comm`` spans the stages of this
-    replica, ``dp_comm`` spans the replicas of this stage."""
+    replica, ``dp_comm`` spans the replicas of this stage.  Ranks beyond ``dp * pp``
+    (idle, like ranks >= 2 in the reference's MP script) get ``(None, None, -1, -1)``.
+    Collective over the world: EVERY rank must call it (group creation is global)."""
     n = world.world_size
-    if dp * pp != n:
-        raise ValueError(f"dp({dp}) x pp({pp}) != world size {n}")
+    if dp * pp > n:
+        raise ValueError(f"dp({dp}) x pp({pp}) > world size {n}")
     me = world.global_rank
-    replica, stage = divmod(me, pp)
-    pp_comm = dp_comm = None
     if n == 1:
         return world, world, 0, 0
+    active = me < dp * pp
+    replica, stage = divmod(me, pp) if active else (-1, -1)
+    pp_comm = dp_comm = None
     for r in range(dp):
         c = world.split([r * pp + s for s in range(pp)])
         if r == replica:

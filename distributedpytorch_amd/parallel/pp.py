@@ -1,0 +1,333 @@
+"""Model-parallel (pipeline) engine: layer stages on different GPUs, device-to-device
+send/recv of activations and gradients over RCCL, micro-batched schedules.
+
+What it generalises (reference multinode-MP/multinodeMP.py:118-167): stage k lives on
+rank k; forward sends the stage's output to k+1; backward receives d(loss)/d(output),
+runs ``output.backward(grad)`` and sends ``input.grad`` to k-1; every stage has its own
+optimizer; the autograd graph is cut at the stage boundary (``.data`` at MP.py:139) and
+re-rooted on a fresh leaf (MP.py:155); the ragged last batch works because the batch
+dimension is taken from the data (MP.py:143,152).
+
+What is different: tensors never touch the host (the reference stages every transfer
+through CPU memory because gloo needs it, MP.py:139,145,155,166); any number of stages;
+the batch is split into micro-batches and scheduled GPipe- or 1F1B-style so stages
+overlap instead of idling (the reference is strictly serial: <= 1/S utilisation);
+sends and receives that are adjacent in the schedule go out as one grouped RCCL call;
+stages can be replicated (DP x PP) with the data-parallel engine reducing each stage's
+gradients inside its replica group.
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import comm as _comm
+from . import schedule as _sched
+
+_DTYPES = [torch.float32, torch.bfloat16, torch.float16, torch.int64, torch.float64]
+
+
+# ---------------------------------------------------------------------------- partitioning
+def partition_balanced(costs: Sequence[float], n_stages: int) -> List[Tuple[int, int]]:
+    """Split ``len(costs)`` consecutive layers into ``n_stages`` contiguous groups minimising
+    the heaviest group (classic linear-partition DP).  Returns [(start, end), ...]."""
+    n = len(costs)
+    if n_stages < 1 or n_stages > n:
+        raise ValueError(f"cannot split {n} layers into {n_stages} stages")
+    prefix = [0.0]
+    for c in costs:
+        prefix.append(prefix[-1] + float(c))
+    INF = float("inf")
+    best = [[INF] * (n + 1) for _ in range(n_stages + 1)]
+    cut = [[0] * (n + 1) for _ in range(n_stages + 1)]
+    best[0][0] = 0.0
+    for k in range(1, n_stages + 1):
+        for i in range(k, n + 1):
+            for j in range(k - 1, i):
+                v = max(best[k - 1][j], prefix[i] - prefix[j])
+                if v < best[k][i]:
+                    best[k][i], cut[k][i] = v, j
+    bounds = []
+    i = n
+    for k in range(n_stages, 0, -1):
+        j = cut[k][i]
+        bounds.append((j, i))
+        i = j
+    return bounds[::-1]
+
+
+def param_costs(layers: Sequence[nn.Module]) -> List[float]:
+    return [1.0 + sum(p.numel() for p in l.parameters()) for l in layers]
+
+
+def measure_costs(layers: Sequence[nn.Module], sample: torch.Tensor, iters: int = 2) -> List[float]:
+    """Forward+backward time of every layer on this device (stages must be balanced by
+    TIME, not by layer count: early ResNet stages move far more activation bytes)."""
+    costs = []
+    x = sample
+    use_cuda = sample.is_cuda
+    for layer in layers:
+        xin = x.detach().requires_grad_(x.is_floating_point())
+        y = layer(xin)
+        g = torch.ones_like(y)
+        if use_cuda:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            xin2 = x.detach().requires_grad_(x.is_floating_point())
+            y2 = layer(xin2)
+            y2.backward(g)
+        if use_cuda:
+            torch.cuda.synchronize()
+        costs.append((time.perf_counter() - t0) / iters)
+        x = y.detach()
+        for p in layer.parameters():
+            p.grad = None
+    return costs
+
+
+def split_microbatches(n: int, n_micro: int) -> List[int]:
+    """Sizes of the micro-batches of a batch of ``n`` samples (ragged batches allowed;
+    empty micro-batches are dropped, so a batch of 3 with 8 micro-batches runs 3)."""
+    n_micro = max(1, min(n_micro, n))
+    base, rem = divmod(n, n_micro)
+    return [base + (1 if i < rem else 0) for i in range(n_micro)]
+
+
+# ---------------------------------------------------------------------------- engine
+class PipelineStage:
+    """One stage of the pipeline, bound to this rank.
+
+    ``comm``      pipeline-group communicator (rank inside it == stage index)
+    ``module``    this stage's layers
+    ``loss_fn``   ``(output, target) -> scalar`` (mean over the micro-batch); last stage only
+    ``dp``        optional ``DataParallel`` engine over the stage's replica group
+    """
+
+    def __init__(self, module: nn.Module, comm: _comm.Communicator, loss_fn: Optional[Callable] = None,
+                 n_micro: int = 1, schedule: str = "1f1b", dp=None, send_dtype: Optional[torch.dtype] = None):
+        self.module, self.comm, self.loss_fn, self.dp = module, comm, loss_fn, dp
+        self.stage, self.n_stages = comm.rank, comm.world_size
+        self.n_micro, self.schedule = n_micro, schedule
+        self.first, self.last = self.stage == 0, self.stage == self.n_stages - 1
+        self.send_dtype = send_dtype
+        self.device = next(module.parameters()).device
+        self._in_meta: Optional[Tuple[Tuple[int, ...], torch.dtype]] = None   # trailing shape + dtype of inputs
+        self._out_meta_sent = False
+        self._pending_sends: List = []
+        self.last_loss: Optional[torch.Tensor] = None
+
+    # ---- shape negotiation: once, trailing dims only (the batch dim comes from the data) ----
+    def _send_meta(self, y: torch.Tensor) -> None:
+        meta = torch.zeros(8, dtype=torch.int64)
+        trailing = list(y.shape[1:])
+        meta[0] = len(trailing)
+        for i, d in enumerate(trailing):
+            meta[1 + i] = d
+        meta[7] = _DTYPES.index(y.dtype)
+        self.comm.send(meta.to(self.device), self.stage + 1)
+        self._out_meta_sent = True
+
+    def _recv_meta(self) -> None:
+        meta = torch.zeros(8, dtype=torch.int64, device=self.device)
+        self.comm.recv(meta, self.stage - 1)
+        meta = meta.cpu()
+        nd = int(meta[0])
+        self._in_meta = (tuple(int(v) for v in meta[1:1 + nd]), _DTYPES[int(meta[7])])
+
+    # ---- one training step over a (possibly ragged) batch ----
+    def train_step(self, batch_size: int, x: Optional[torch.Tensor] = None, target: Optional[torch.Tensor] = None):
+        """``x`` is needed on the first stage, ``target`` on the last; every stage passes
+        the same ``batch_size`` (each rank walks its own loader, as in the reference).
+        Returns the mean loss over the batch on the last stage, else None.  Gradients are
+        accumulated into ``.grad``; the caller steps its own optimizer afterwards."""
+        sizes = split_microbatches(batch_size, self.n_micro)
+        n_micro = len(sizes)
+        offs = [0]
+        for s in sizes:
+            offs.append(offs[-1] + s)
+        ops = _sched.build_schedule(self.schedule, self.n_stages, self.stage, n_micro)
+        steps = _sched.group_comm(ops)
+        inputs: Dict[int, torch.Tensor] = {}
+        outputs: Dict[int, torch.Tensor] = {}
+        grads_in: Dict[int, torch.Tensor] = {}
+        loss_sum = None
+        n_b_done = 0
+        if not self.first and self._in_meta is None:
+            self._recv_meta()
+
+        for step in steps:
+            kind = step[0][0]
+            if kind in _sched.COMM_OPS:
+                self._run_comm(step, sizes, inputs, outputs, grads_in)
+                continue
+            op, mb = step[0]
+            if op == "F":
+                if self.first:
+                    xin = x[offs[mb]:offs[mb + 1]]
+                else:
+                    xin = inputs[mb]
+                    if xin.is_floating_point():
+                        xin.requires_grad_(True)
+                    inputs[mb] = xin
+                y = self.module(xin)
+                if self.last:
+                    t = target[offs[mb]:offs[mb + 1]]
+                    loss = self.loss_fn(y, t) * (sizes[mb] / float(batch_size))
+                    outputs[mb] = loss
+                    loss_sum = loss.detach() if loss_sum is None else loss_sum + loss.detach()
+                else:
+                    outputs[mb] = y
+                    if not self._out_meta_sent:
+                        self._send_meta(y)
+            else:  # "B"
+                n_b_done += 1
+                sync_now = n_b_done == n_micro
+                ctx = self.dp.no_sync() if (self.dp is not None and not sync_now) else _NullCtx()
+                with ctx:
+                    if self.last:
+                        outputs.pop(mb).backward()
+                    else:
+                        outputs.pop(mb).backward(grads_in.pop(mb))
+                if self.first:
+                    inputs.pop(mb, None)
+        for w in self._pending_sends:
+            w[0].wait()
+        self._pending_sends.clear()
+        if self.dp is not None:
+            self.dp.finish()
+        self.last_loss = loss_sum
+        return loss_sum
+
+    def _run_comm(self, step, sizes, inputs, outputs, grads_in) -> None:
+        batch_ops = []
+        recvs = []
+        for op, mb in step:
+            if op == "send_fwd":
+                y = outputs[mb].detach()
+                if self.send_dtype is not None and y.dtype != self.send_dtype:
+                    y = y.to(self.send_dtype)
+                y = y.contiguous()
+                batch_ops.append(("send", y, self.stage + 1))
+            elif op == "recv_fwd":
+                shape, dtype = self._in_meta
+                buf = torch.empty((sizes[mb],) + shape, dtype=dtype, device=self.device)
+                batch_ops.append(("recv", buf, self.stage - 1))
+                recvs.append(("in", mb, buf))
+            elif op == "send_bwd":
+                xin = inputs.pop(mb)
+                g = xin.grad if xin.grad is not None else torch.zeros_like(xin)
+                batch_ops.append(("send", g.contiguous(), self.stage - 1))
+            elif op == "recv_bwd":
+                y = outputs[mb]
+                buf = torch.empty(y.shape, dtype=y.dtype if self.send_dtype is None else self.send_dtype, device=self.device)
+                batch_ops.append(("recv", buf, self.stage + 1))
+                recvs.append(("grad", mb, buf))
+        works = self.comm.batch_p2p(batch_ops)
+        # receives must complete before the compute that follows; sends complete lazily
+        if len(works) == len(batch_ops):
+            for (kind, t, _), w in zip(batch_ops, works):
+                if kind == "recv":
+                    w.wait()
+                else:
+                    self._pending_sends.append((w, t))
+        else:  # backend coalesced the group into fewer handles
+            for w in works:
+                w.wait()
+        for kind, mb, buf in recvs:
+            if kind == "in":
+                inputs[mb] = buf
+            else:
+                y = outputs[mb]
+                grads_in[mb] = buf if buf.dtype == y.dtype else buf.to(y.dtype)
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def build_stage_module(layers: Sequence[nn.Module], bounds: Sequence[Tuple[int, int]], stage: int,
+                       model: Optional[nn.Module] = None) -> nn.Module:
+    """This stage's layers as one module.  When the full ``model`` is given, the stage
+    remembers the model-level name of every state_dict entry (``_dpa_key_map``) so stage
+    checkpoints merge back into ONE state_dict with the original keys."""
+    a, b = bounds[stage]
+    mod = layers[a] if b - a == 1 else nn.Sequential(*layers[a:b])
+    if model is not None:
+        global_names = {id(t): k for k, t in model.state_dict(keep_vars=True).items()}
+        mod._dpa_key_map = {k: global_names[id(t)] for k, t in mod.state_dict(keep_vars=True).items()
+                            if id(t) in global_names}
+    return mod
+
+
+# ---------------------------------------------------------------------------- benchmark driver
+def run_pipeline_bench(args, world: _comm.Communicator, device: torch.device) -> dict:
+    """``bench.py --pipeline S``: S-stage micro-batched pipeline (x replicas when
+    world_size > S), same images/sec metric.  Stages are balanced by measured time."""
+    from ..models import resnet
+    from ..optim import FusedSGD
+    from .dp import DataParallel
+    from .flat import FlatParams
+    from .. import ops
+
+    S = args.pipeline
+    n = world.world_size
+    if n % S != 0:
+        raise SystemExit(f"world size {n} is not a multiple of --pipeline {S}")
+    replicas = n // S
+    pp_comm, dp_comm, replica, stage = _comm.build_grid(world, replicas, S)
+    name = args.model if args.model in ("resnet50", "resnet152", "tiny_resnet") else "resnet152"
+    model = resnet.tiny_resnet() if name == "tiny_resnet" else getattr(resnet, name)()
+    hw, classes = (64, 16) if name == "tiny_resnet" else (224, 1000)
+    batch = args.batch or 256
+    model = model.to(device).train()
+    layers = model.pipeline_layers()
+    mb = max(1, batch // args.micro_batches)
+    g = torch.Generator(device=device).manual_seed(1234 + replica)
+    x = torch.randn(batch, 3, hw, hw, generator=g, device=device)
+    y = torch.randint(0, classes, (batch,), generator=g, device=device)
+    costs = measure_costs(layers, x[:mb]) if device.type == "cuda" else param_costs(layers)
+    # every rank must agree on the split: use stage 0 / replica 0's measurement
+    costs = world.broadcast_object(costs, src=0)
+    bounds = partition_balanced(costs, S)
+    stage_mod = build_stage_module(layers, bounds, stage, model)
+    del model
+    dp = DataParallel(stage_mod, dp_comm, bucket_mb=args.bucket_mb, first_bucket_mb=args.first_bucket_mb,
+                      use_sink=not args.no_sink)
+    opt = FusedSGD(dp.flat, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    opt.grad_scale = dp.grad_scale
+    loss_fn = (lambda out, t: ops.softmax_cross_entropy(out, t, classes))
+    eng = PipelineStage(stage_mod, pp_comm, loss_fn, n_micro=args.micro_batches, schedule=args.schedule, dp=dp)
+
+    def step():
+        loss = eng.train_step(batch, x if eng.first else None, y if eng.last else None)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    world.barrier()
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(args.steps):
+        loss = step()
+    world.barrier()
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    elapsed = world.all_reduce_scalar(time.perf_counter() - t0, "max")
+    lossv = float(loss.float().cpu()) if loss is not None else float("nan")
+    # the loss lives on the last stage; make rank 0 report it
+    lossv = world.all_reduce_scalar(lossv if eng.last and replica == 0 else 0.0, "sum")
+    return {"elapsed": elapsed, "items_per_rank_step": batch, "dp_world": replicas, "loss": lossv,
+            "config": {"model": name, "global_batch": batch * replicas, "image": f"3x{hw}x{hw}",
+                       "parallelism": f"pp{S}xdp{replicas}", "micro_batches": args.micro_batches,
+                       "schedule": args.schedule, "stage_bounds": bounds}}

@@ -1,0 +1,191 @@
+"""Training loops: the reference's two ``run()`` functions, re-built on the engines.
+
+``run_dp``  = multinode-DP/multinodeDP.py:131-157 (synchronous data-parallel SGD)
+``run_mp``  = multinode-MP/multinodeMP.py:102-170 (model parallel; here an S-stage,
+              micro-batched pipeline, optionally replicated)
+
+Both are ``fn(local_rank, global_rank, world_size, cfg)`` targets for ``launch.spawn``
+(reference: ``init_processes`` then ``run``, DP.py:159-162 / MP.py:172-178).
+"""
+from __future__ import annotations
+
+import os
+from math import ceil
+
+import torch
+
+from . import comm as dcomm
+from . import data as ddata
+from . import metrics as dmetrics
+from .checkpoint import load_checkpoint, save_checkpoint
+from .config import TrainConfig
+from .optim import FusedSGD
+from .parallel.dp import DataParallel
+from .parallel.flat import FlatParams
+from .parallel.pp import PipelineStage, build_stage_module, partition_balanced, param_costs
+
+
+def pick_device(cfg: TrainConfig, local_rank: int) -> torch.device:
+    want = cfg.device
+    if want == "auto":
+        want = "cuda" if (torch.cuda.is_available() and cfg.backend not in ("gloo",)) else "cpu"
+    if want == "cuda":
+        torch.cuda.set_device(local_rank)
+        return torch.device("cuda", local_rank)
+    return torch.device("cpu")
+
+
+def build_model(name: str):
+    """Returns (model, dataset_kind, loss(model, x, y), use_lp, classes)."""
+    from . import ops
+    if name == "mnist_cnn":
+        from .models import mnist
+        m = mnist.Net()
+        return m, "mnist", (lambda mod, x, y: mnist.nll_loss(mod(x), y)), False, 10
+    if name in ("resnet50", "resnet101", "resnet152", "tiny_resnet"):
+        from .models import resnet
+        m = getattr(resnet, name)()
+        return m, ("tiny_image" if name == "tiny_resnet" else "imagenet"), (lambda mod, x, y: mod.loss(x, y)), True, m.num_classes
+    if name in ("gpt2", "gpt2_small", "gpt2_tiny"):
+        from .models import gpt2
+        m = gpt2.gpt2_tiny() if name == "gpt2_tiny" else gpt2.gpt2_small()
+        return m, "tokens", (lambda mod, x, y: mod.loss(x, y)), True, m.cfg.vocab_size
+    raise ValueError(f"unknown model {name!r}")
+
+
+def build_dataset(kind: str, cfg: TrainConfig, classes: int, model=None):
+    if kind == "mnist":
+        return ddata.SyntheticImageDataset(cfg.dataset_size, (1, 28, 28), 10, cfg.seed)
+    if kind == "imagenet":
+        return ddata.SyntheticImageDataset(cfg.dataset_size, (3, 224, 224), classes, cfg.seed)
+    if kind == "tiny_image":
+        return ddata.SyntheticImageDataset(cfg.dataset_size, (3, 64, 64), classes, cfg.seed)
+    if kind == "tokens":
+        c = model.cfg
+        return ddata.SyntheticTokenDataset(cfg.dataset_size, min(c.n_positions, 1024), c.vocab_size, cfg.seed)
+    raise ValueError(kind)
+
+
+def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig):
+    """Distributed synchronous SGD (reference DP.py:131-157)."""
+    device = pick_device(cfg, local_rank)
+    dcomm.set_sync_debug(cfg.sync_debug)
+    comm = dcomm.init_process_group(cfg.backend, cfg.dist_url, global_rank, world_size, cfg.timeout_s, device)
+    try:
+        torch.manual_seed(cfg.seed)                      # identical initial replicas (DP.py:138) ...
+        model, kind, loss_fn, use_lp, classes = build_model(cfg.model)
+        model = model.to(device).train()
+        dataset = build_dataset(kind, cfg, classes, model)
+        loader, bsz = ddata.partition_dataset(dataset, comm.rank, comm.world_size, cfg.batch_size, cfg.seed, device)
+        dp = DataParallel(model, comm, bucket_mb=cfg.bucket_mb, first_bucket_mb=cfg.first_bucket_mb,
+                          use_lp=use_lp)                 # ... and a broadcast from rank 0 for safety
+        opt = FusedSGD(dp.flat, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
+        opt.grad_scale = dp.grad_scale                   # the `/= world_size` of DP.py:129, fused
+        start_epoch = 0
+        if cfg.resume:
+            payload = load_checkpoint(cfg.resume, model, opt, flat=dp.flat)
+            start_epoch = int(payload.get("epoch", -1)) + 1
+        log = dmetrics.JsonlLogger(cfg.log_json, global_rank)
+        meter = dmetrics.ThroughputMeter(device)
+        num_batches = ceil(len(loader.dataset) / float(bsz))          # DP.py:145
+        if cfg.steps_per_epoch:
+            num_batches = min(num_batches, cfg.steps_per_epoch)
+        last = None
+        for epoch in range(start_epoch, cfg.epochs):
+            loader.set_epoch(epoch)
+            epoch_loss = torch.zeros((), device=device)
+            meter.reset(); meter.start()
+            for step, (x, y) in enumerate(loader):
+                if cfg.steps_per_epoch and step >= cfg.steps_per_epoch:
+                    break
+                loss = loss_fn(model, x, y)
+                epoch_loss += loss.detach()              # stays on device: no host sync (DP.py:153)
+                loss.backward()
+                dp.finish()                              # bucketed all-reduce, overlapped with backward
+                if cfg.sync_debug:
+                    dmetrics.check_reduced_gradients(dp.flat, comm)
+                opt.step()                               # fused: scale, momentum, update, bf16 shadow, zero grad
+                meter.update(x.shape[0])
+            last = float(epoch_loss / num_batches)
+            rate = meter.rate()
+            print(dmetrics.epoch_line_dp(comm.rank, epoch, last), flush=True)            # DP.py:157
+            total = comm.all_reduce_scalar(rate, "sum")
+            if comm.rank == 0:
+                print(f"[dp] epoch {epoch}: {total:.1f} samples/s whole job ({rate:.1f}/rank, {meter.ms_per_step():.2f} ms/step)", flush=True)
+            log.log(kind="dp_epoch", epoch=epoch, loss=last, samples_per_sec=total, world_size=world_size)
+            if cfg.checkpoint:
+                save_checkpoint(cfg.checkpoint, model, opt, epoch, comm=comm)
+        return last
+    finally:
+        comm.barrier()
+        dcomm.destroy_process_group()
+
+
+def run_mp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig):
+    """Model-parallel training (reference MP.py:102-170), generalised to S micro-batched stages."""
+    device = pick_device(cfg, local_rank)
+    dcomm.set_sync_debug(cfg.sync_debug)
+    world = dcomm.init_process_group(cfg.backend, cfg.dist_url, global_rank, world_size, cfg.timeout_s, device)
+    try:
+        stages = cfg.stages
+        replicas = max(1, cfg.dp_replicas)
+        if stages * replicas > world_size:
+            raise ValueError(f"{stages} stages x {replicas} replicas need {stages * replicas} ranks, have {world_size}")
+        # ranks beyond stages*replicas idle, like ranks >= 2 in the reference (MP.py:118-124 only uses 0 and 1)
+        pp_comm, dp_comm, replica, stage = dcomm.build_grid(world, replicas, stages)
+        if stage < 0:
+            return None
+        torch.manual_seed(cfg.seed)
+        from . import ops
+        if cfg.model == "mnist_cnn":
+            from .models import mnist
+            full = None
+            if stages != 2:
+                raise ValueError("the MNIST model-parallel example has exactly 2 stages (Net1 | Net2)")
+            layers = mnist.mnist_stages()                 # stage k on rank k (MP.py:118-124)
+            stage_mod = layers[stage]
+            loss_fn = mnist.nll_loss
+            kind, classes, use_lp = "mnist", 10, False
+        else:
+            full, kind, _, use_lp, classes = build_model(cfg.model)
+            layers = full.pipeline_layers()
+            bounds = partition_balanced(param_costs(layers), stages)
+            stage_mod = build_stage_module(layers, bounds, stage, full)
+            loss_fn = (lambda out, t: ops.softmax_cross_entropy(out.reshape(-1, out.shape[-1]), t.reshape(-1), classes))
+        stage_mod = stage_mod.to(device).train()
+        dataset = build_dataset(kind, cfg, classes, full)
+        # every rank walks the SAME un-shuffled loader (MP.py:104-116): stage 0 consumes the data, the
+        # last stage the targets; replicas take disjoint shards
+        if replicas > 1:
+            part = ddata.DataPartitioner(dataset, [1.0 / replicas] * replicas, cfg.seed).use(replica)
+        else:
+            part = ddata.Partition(dataset, list(range(len(dataset))))
+        loader = ddata.BatchLoader(part, cfg.batch_size, shuffle=False, device=device)
+        dp = DataParallel(stage_mod, dp_comm, use_lp=use_lp) if (dp_comm is not None) else None
+        flat = dp.flat if dp is not None else FlatParams(stage_mod, use_lp=use_lp)
+        opt = FusedSGD(flat, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)   # one optimizer per stage
+        if dp is not None:
+            opt.grad_scale = dp.grad_scale
+        eng = PipelineStage(stage_mod, pp_comm, loss_fn, n_micro=cfg.micro_batches, schedule=cfg.schedule, dp=dp)
+        if cfg.resume:
+            load_checkpoint(cfg.resume, stage_mod, None, strict=False, flat=flat)
+        log = dmetrics.JsonlLogger(cfg.log_json, global_rank, only_rank0=False)
+        meter = dmetrics.ThroughputMeter(device)
+        loss = None
+        for epoch in range(cfg.epochs):
+            meter.reset(); meter.start()
+            for step, (x, y) in enumerate(loader):
+                if cfg.steps_per_epoch and step >= cfg.steps_per_epoch:
+                    break
+                loss = eng.train_step(x.shape[0], x if eng.first else None, y if eng.last else None)
+                opt.step()
+                meter.update(x.shape[0])
+            if eng.last and replica == 0:
+                print(dmetrics.epoch_line_mp(epoch, loss), flush=True)                      # MP.py:169-170
+                log.log(kind="mp_epoch", epoch=epoch, loss=float(loss), samples_per_sec=meter.rate() * replicas)
+            if cfg.checkpoint:
+                save_checkpoint(cfg.checkpoint, stage_mod, opt, epoch, comm=dp_comm, pipeline_comm=pp_comm)
+        return float(loss) if loss is not None else None
+    finally:
+        world.barrier()
+        dcomm.destroy_process_group()

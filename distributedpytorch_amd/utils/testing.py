@@ -1,0 +1,131 @@
+"""Worker functions for the multi-process CPU (gloo) tests.  They live in the package so
+that ``spawn`` children can import them by module path."""
+from __future__ import annotations
+
+import os
+import time
+
+import torch
+
+from .. import comm as dcomm
+from ..optim import FusedSGD
+from ..parallel.dp import DataParallel
+from ..parallel.flat import FlatParams
+from ..parallel.pp import PipelineStage, build_stage_module, partition_balanced, param_costs
+
+
+def free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _make_model(name: str):
+    torch.manual_seed(1234)
+    if name == "mnist":
+        from ..models import mnist
+        m = mnist.Net()
+        m.conv2_drop.p = 0.0
+        m.eval()       # dropout off so single-process and distributed runs are comparable
+        return m, (lambda mod, x, y: mnist.nll_loss(mod(x), y)), (1, 28, 28), 10
+    from ..models import resnet
+    m = resnet.tiny_resnet()
+    return m.train(), (lambda mod, x, y: mod.loss(x, y)), (3, 32, 32), 16
+
+
+def _data(shape, classes, n, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, *shape, generator=g), torch.randint(0, classes, (n,), generator=g)
+
+
+def dp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, bucket_kb, steps):
+    """Each rank takes its shard of ONE global batch; writes reduced grads + params."""
+    comm = dcomm.init_process_group("gloo", url, global_rank, world_size, 60.0, torch.device("cpu"))
+    model, loss_fn, shape, classes = _make_model(model_name)
+    n_global = 8 * world_size
+    x, y = _data(shape, classes, n_global)
+    per = n_global // world_size
+    xs, ys = x[global_rank * per:(global_rank + 1) * per], y[global_rank * per:(global_rank + 1) * per]
+    dp = DataParallel(model, comm, bucket_mb=bucket_kb / 1024.0, first_bucket_mb=bucket_kb / 4096.0)
+    opt = FusedSGD(dp.flat, lr=0.05, momentum=0.5)
+    opt.grad_scale = dp.grad_scale
+    losses = []
+    for s in range(steps):
+        loss = loss_fn(model, xs, ys)
+        loss.backward()
+        dp.finish()
+        if s == 0:
+            g = dp.flat.grad.clone() * dp.grad_scale
+            torch.save({n: g[dp.flat.offsets[i]:dp.flat.offsets[i] + p.numel()].view(p.shape).clone()
+                        for i, (n, p) in enumerate(zip(dp.flat.names, dp.flat.params))},
+                       os.path.join(out_dir, f"grads_{global_rank}.pt"))
+        opt.step()
+        losses.append(float(loss.detach()))
+    torch.save({"losses": losses, "params": {n: p.detach().clone() for n, p in model.named_parameters()},
+                "buckets": len(dp.buckets), "calls": dp.stats["allreduce_calls"]},
+               os.path.join(out_dir, f"final_{global_rank}.pt"))
+    comm.barrier()
+    dcomm.destroy_process_group()
+
+
+def pp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, stages, replicas, n_micro, schedule, batch, steps):
+    """Pipeline (x replicas) on gloo; writes per-stage grads after the first step and losses."""
+    world = dcomm.init_process_group("gloo", url, global_rank, world_size, 60.0, torch.device("cpu"))
+    pp_comm, dp_comm, replica, stage = dcomm.build_grid(world, replicas, stages)
+    if stage >= 0:
+        torch.manual_seed(1234)
+        if model_name == "mnist":
+            from ..models import mnist
+            layers = mnist.mnist_stages()
+            stage_mod = layers[stage]
+            loss_fn, shape, classes = mnist.nll_loss, (1, 28, 28), 10
+        else:
+            from ..models import resnet
+            from .. import ops
+            full = resnet.tiny_resnet().train()
+            layers = full.pipeline_layers()
+            bounds = partition_balanced(param_costs(layers), stages)
+            stage_mod = build_stage_module(layers, bounds, stage, full)
+            loss_fn, shape, classes = (lambda o, t: ops.softmax_cross_entropy(o, t, 16)), (3, 32, 32), 16
+        x, y = _data(shape, classes, batch * replicas)
+        x, y = x[replica * batch:(replica + 1) * batch], y[replica * batch:(replica + 1) * batch]
+        dp = DataParallel(stage_mod, dp_comm) if replicas > 1 else None
+        flat = dp.flat if dp is not None else FlatParams(stage_mod)
+        opt = FusedSGD(flat, lr=0.05, momentum=0.0)
+        if dp is not None:
+            opt.grad_scale = dp.grad_scale
+        eng = PipelineStage(stage_mod, pp_comm, loss_fn, n_micro=n_micro, schedule=schedule, dp=dp)
+        losses = []
+        for s in range(steps):
+            loss = eng.train_step(batch, x if eng.first else None, y if eng.last else None)
+            if s == 0:
+                scale = opt.grad_scale if dp is not None else 1.0
+                torch.save({n: (p.grad * scale).clone() for n, p in stage_mod.named_parameters()},
+                           os.path.join(out_dir, f"grads_r{replica}_s{stage}.pt"))
+            opt.step()
+            if loss is not None:
+                losses.append(float(loss))
+        torch.save({"losses": losses}, os.path.join(out_dir, f"final_r{replica}_s{stage}.pt"))
+        from ..checkpoint import save_checkpoint
+        save_checkpoint(os.path.join(out_dir, f"ckpt_r{replica}.pt"), stage_mod, opt, 0, comm=dp_comm, pipeline_comm=pp_comm)
+    world.barrier()
+    dcomm.destroy_process_group()
+
+
+def crash_worker(local_rank, global_rank, world_size, url):
+    """Rank 1 dies before the collective; the others would hang forever without the launcher's monitor."""
+    comm = dcomm.init_process_group("gloo", url, global_rank, world_size, 120.0, torch.device("cpu"))
+    if global_rank == 1:
+        raise RuntimeError("injected failure on rank 1")
+    time.sleep(0.5)
+    t = torch.ones(4)
+    comm.all_reduce(t)          # blocks: rank 1 never arrives
+    time.sleep(600)
+
+
+def ok_worker(local_rank, global_rank, world_size, out_dir):
+    with open(os.path.join(out_dir, f"rank_{global_rank}.txt"), "w") as f:
+        f.write(f"{local_rank} {global_rank} {world_size} {os.environ.get('RANK')} {os.environ.get('LOCAL_RANK')}")

@@ -1,0 +1,59 @@
+"""T1: data-parallel engine over the gloo loopback backend, world_size 2 and 4.
+Asserts the reference's semantics (DP.py:118-129): after the all-reduce every rank holds
+the MEAN of the per-rank gradients, replicas stay identical, loss goes down."""
+import os
+
+import pytest
+import torch
+
+from distributedpytorch_amd import launch
+from distributedpytorch_amd.utils import testing as T
+
+
+def _reference_mean_grads(model_name, world):
+    model, loss_fn, shape, classes = T._make_model(model_name)
+    x, y = T._data(shape, classes, 8 * world)
+    per = 8
+    acc = None
+    for r in range(world):
+        model.zero_grad()
+        loss_fn(model, x[r * per:(r + 1) * per], y[r * per:(r + 1) * per]).backward()
+        g = {n: p.grad.clone() for n, p in model.named_parameters()}
+        acc = g if acc is None else {n: acc[n] + g[n] for n in g}
+    return {n: v / world for n, v in acc.items()}
+
+
+@pytest.mark.parametrize("model_name,world,bucket_kb", [("mnist", 2, 1024), ("mnist", 4, 8), ("tiny_resnet", 2, 16)])
+def test_dp_gradients_are_the_mean_and_replicas_agree(tmp_path, model_name, world, bucket_kb):
+    url = f"tcp://127.0.0.1:{T.free_port()}"
+    launch.spawn(T.dp_worker, [world], 0, args=(url, model_name, str(tmp_path), bucket_kb, 4))
+    ref = _reference_mean_grads(model_name, world)
+    grads = [torch.load(tmp_path / f"grads_{r}.pt", weights_only=True) for r in range(world)]
+    for name, g in ref.items():
+        for r in range(world):
+            assert torch.allclose(grads[r][name], g, rtol=1e-4, atol=1e-6), f"{name} on rank {r}"
+    finals = [torch.load(tmp_path / f"final_{r}.pt", weights_only=True) for r in range(world)]
+    for r in range(1, world):
+        for name in finals[0]["params"]:
+            assert torch.equal(finals[0]["params"][name], finals[r]["params"][name]), f"replicas diverged at {name}"
+    if model_name == "mnist":
+        if bucket_kb >= 1024:
+            assert finals[0]["buckets"] == 1 and finals[0]["calls"] == 4      # ONE all-reduce per step (reference: 8)
+        else:
+            assert finals[0]["buckets"] > 1
+        # per-rank loss on a fixed shard must go down over 4 SGD steps
+        assert finals[0]["losses"][-1] < finals[0]["losses"][0]
+
+
+def test_baseline_config1_small_cnn_dp_gloo_world2(tmp_path, capfd):
+    """BASELINE.json config 1: small CNN, synthetic MNIST-shape data, DP via spawn on CPU/gloo, world 2."""
+    from distributedpytorch_amd.examples import dp
+    port = T.free_port()
+    ck = tmp_path / "ck.pt"
+    dp.main([f"--dist-url=tcp://127.0.0.1:{port}", "--backend=gloo", "--node-index=0", "--GPU-list=2", "--epochs=2",
+             "--dataset-size=512", "--steps-per-epoch=4", f"--checkpoint={ck}", f"--log-json={tmp_path / 'log.jsonl'}"])
+    out = capfd.readouterr().out
+    assert "Rank  0  , epoch  0  :" in out and "Rank  1  , epoch  1  :" in out       # the reference's per-rank epoch line
+    sd = torch.load(str(ck) + ".model", weights_only=True)
+    assert list(sd.keys()) == ["conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"]
+    assert os.path.exists(tmp_path / "log.jsonl")

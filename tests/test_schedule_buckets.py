@@ -1,0 +1,72 @@
+"""T0: pure-function planners - pipeline schedules, stage partitioner, bucket planner."""
+import pytest
+
+from distributedpytorch_amd.parallel import schedule as S
+from distributedpytorch_amd.parallel.flat import plan_buckets
+from distributedpytorch_amd.parallel.pp import partition_balanced, split_microbatches
+
+
+@pytest.mark.parametrize("kind", ["serial", "gpipe", "1f1b"])
+@pytest.mark.parametrize("stages", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("micro", [1, 2, 4, 7, 16])
+def test_schedules_are_consistent_and_deadlock_free(kind, stages, micro):
+    S.validate(kind, stages, micro)
+
+
+def test_serial_schedule_is_the_reference_order():
+    # stage 0: forward, send, wait for grad, backward (MP.py:133-146)
+    assert S.build_schedule("serial", 2, 0, 1) == [("F", 0), ("send_fwd", 0), ("recv_bwd", 0), ("B", 0)]
+    # stage 1: recv, forward, backward, send grad (MP.py:151-167)
+    assert S.build_schedule("serial", 2, 1, 1) == [("recv_fwd", 0), ("F", 0), ("B", 0), ("send_bwd", 0)]
+
+
+def test_1f1b_bounds_live_activations():
+    for stages in (2, 4, 8):
+        for stage in range(stages):
+            assert S.peak_live_microbatches("1f1b", stages, stage, 32) <= stages - stage
+            assert S.peak_live_microbatches("gpipe", stages, stage, 32) == 32
+    assert abs(S.bubble_fraction(4, 8) - 3 / 11) < 1e-12
+
+
+def test_1f1b_groups_send_with_recv():
+    steps = S.group_comm(S.build_schedule("1f1b", 4, 1, 8))
+    assert [("send_fwd", 2), ("recv_bwd", 0)] in steps or any(len(s) == 2 and s[0][0] == "send_fwd" and s[1][0] == "recv_bwd" for s in steps)
+    assert any(len(s) == 2 and s[0][0] == "send_bwd" and s[1][0] == "recv_fwd" for s in steps)
+
+
+def test_partition_balanced():
+    assert partition_balanced([1, 1, 1, 1], 2) == [(0, 2), (2, 4)]
+    b = partition_balanced([10, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1], 2)
+    assert b == [(0, 1), (1, 11)]
+    costs = [3, 1, 4, 1, 5, 9, 2, 6, 5, 3, 5]
+    for k in (1, 2, 3, 4, 11):
+        b = partition_balanced(costs, k)
+        assert b[0][0] == 0 and b[-1][1] == len(costs) and all(b[i][1] == b[i + 1][0] for i in range(k - 1))
+        assert all(e > s for s, e in b)
+    with pytest.raises(ValueError):
+        partition_balanced([1, 2], 3)
+
+
+def test_split_microbatches_ragged():
+    assert split_microbatches(256, 8) == [32] * 8
+    assert split_microbatches(96, 8) == [12] * 8            # reference's ragged last batch at B=256
+    assert split_microbatches(12, 8) == [2, 2, 2, 2, 1, 1, 1, 1]
+    assert split_microbatches(3, 8) == [1, 1, 1]
+    assert sum(split_microbatches(608, 7)) == 608
+
+
+def test_plan_buckets():
+    numels = [10, 10, 64, 500, 5, 5]
+    offsets, cur = [], 0
+    for n in numels:
+        offsets.append(cur); cur += (n + 63) // 64 * 64
+    order = list(range(len(numels)))
+    # everything fits: ONE bucket (the small CNN's 87 KB of grads -> one all-reduce)
+    b = plan_buckets(numels, offsets, order, cur, bucket_bytes=1 << 20)
+    assert len(b) == 1 and b[0].start == 0 and b[0].end == cur and b[0].param_indices == order
+    # small cap: buckets close on parameter boundaries, cover the buffer exactly, in order
+    b = plan_buckets(numels, offsets, order, cur, bucket_bytes=100 * 4, first_bucket_bytes=12 * 4)
+    assert b[0].param_indices == [0]
+    assert [x.start for x in b][0] == 0 and b[-1].end == cur
+    assert all(b[i].end == b[i + 1].start for i in range(len(b) - 1))
+    assert sorted(sum((x.param_indices for x in b), [])) == order
