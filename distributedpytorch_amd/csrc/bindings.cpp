@@ -29,7 +29,7 @@ struct Guard {
 // ---------------------------------------------------------------- conv
 // x [N,H,W,C] bf16, w [K,R,S,C] bf16 -> y [N,Ho,Wo,K] bf16 (+ optional BN partial stats [rows,2,K])
 std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias, int64_t stride,
-                               int64_t pad, int64_t act, bool want_stats) {
+                               int64_t pad, int64_t act, bool want_stats, const c10::optional<Tensor>& stats_buf) {
     CHECK_BF16(x); CHECK_BF16(w);
     TORCH_CHECK(x.dim() == 4 && w.dim() == 4, "conv_fprop: x and w must be 4-D (NHWC / KRSC)");
     const int64_t N = x.size(0), H = x.size(1), W = x.size(2), C = x.size(3);
@@ -39,7 +39,8 @@ std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::opti
     TORCH_CHECK(stride >= 1 && pad >= 0, "bad stride/pad");
     const int64_t Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     TORCH_CHECK(Ho > 0 && Wo > 0, "conv_fprop: empty output");
-    TORCH_CHECK(N * H * W * C < (1ll << 40) && N * Ho * Wo < (1ll << 31), "conv_fprop: tensor too large");
+    TORCH_CHECK(x.numel() < (1ll << 31) && w.numel() < (1ll << 31) && N * Ho * Wo * K < (1ll << 40),
+                "conv_fprop: operands must have fewer than 2^31 elements (32-bit gather offsets)");
     Guard g(x);
     Tensor y = torch::empty({N, Ho, Wo, K}, x.options());
     dpa::ConvArgs a{};
@@ -53,10 +54,18 @@ std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::opti
     Tensor stats;
     a.stats = nullptr;
     const int64_t M = N * Ho * Wo;
+    a.stats_rows = 0; a.addend = nullptr;
     if (want_stats) {
-        stats = torch::empty({dpa::conv_stats_rows(M), 2, K}, x.options().dtype(at::kFloat));
-        a.stats = stats.data_ptr<float>();
         TORCH_CHECK(act == 0, "stats need a linear epilogue");
+        if (stats_buf.has_value() && stats_buf->defined()) {   // persistent buffer: zero on entry, re-zeroed by bn_finalize
+            stats = *stats_buf;
+            CHECK_F32(stats);
+            TORCH_CHECK(stats.dim() == 3 && stats.size(1) == 2 && stats.size(2) == K && stats.size(0) >= 1, "stats_buf must be [rows,2,K]");
+        } else {
+            stats = torch::zeros({dpa::conv_stats_rows(M), 2, K}, x.options().dtype(at::kFloat));
+        }
+        a.stats = stats.data_ptr<float>();
+        a.stats_rows = stats.size(0);
     }
     a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.Ho = Ho; a.Wo = Wo;
     a.stride = stride; a.pad = pad; a.mode = 0; a.act = act;
@@ -66,7 +75,8 @@ std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::opti
 }
 
 // dgrad: dy [N,Ho,Wo,K] bf16, wt [C,R,S,K] bf16 (filter with K and C swapped) -> dx [N,H,W,C]
-Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int64_t stride, int64_t pad) {
+Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int64_t stride, int64_t pad,
+                  const c10::optional<Tensor>& addend) {
     CHECK_BF16(dy); CHECK_BF16(wt);
     TORCH_CHECK(dy.dim() == 4 && wt.dim() == 4, "conv_dgrad: 4-D tensors expected");
     const int64_t N = dy.size(0), Ho = dy.size(1), Wo = dy.size(2), K = dy.size(3);
@@ -78,6 +88,13 @@ Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int6
     Tensor dx = torch::empty({N, H, W, C}, dy.options());
     dpa::ConvArgs a{};
     a.x = dy.data_ptr(); a.w = wt.data_ptr(); a.y = dx.data_ptr(); a.bias = nullptr; a.stats = nullptr;
+    a.stats_rows = 0; a.addend = nullptr;
+    TORCH_CHECK(dy.numel() < (1ll << 31) && wt.numel() < (1ll << 31), "conv_dgrad: operands must have fewer than 2^31 elements");
+    if (addend.has_value() && addend->defined()) {
+        CHECK_BF16((*addend));
+        TORCH_CHECK(addend->numel() == N * H * W * C, "conv_dgrad: addend shape");
+        a.addend = addend->data_ptr();
+    }
     a.N = N; a.H = Ho; a.W = Wo; a.C = K; a.K = C; a.R = R; a.S = S; a.Ho = H; a.Wo = W;
     a.stride = stride; a.pad = pad; a.mode = 1; a.act = 0;
     dpa::conv_igemm(a, cur_stream());
@@ -94,6 +111,7 @@ void conv_wgrad(const Tensor& x, const Tensor& dy, Tensor& dw, int64_t stride, i
     TORCH_CHECK(dy.size(0) == N && dw.size(0) == K && dw.size(3) == C, "conv_wgrad: shape mismatch");
     TORCH_CHECK((H + 2 * pad - R) / stride + 1 == Ho && (W + 2 * pad - S) / stride + 1 == Wo, "conv_wgrad: geometry mismatch");
     TORCH_CHECK(C % 8 == 0 && K % 8 == 0, "conv_wgrad: channels must be multiples of 8");
+    TORCH_CHECK(x.numel() < (1ll << 40) && dy.numel() < (1ll << 40), "conv_wgrad: tensor too large");
     Guard g(x);
     dpa::WgradArgs a{};
     a.x = x.data_ptr(); a.dy = dy.data_ptr(); a.dw = dw.data_ptr<float>();
@@ -132,7 +150,7 @@ Tensor bn_stats(const Tensor& x) {
 // stats [rows,2,C] -> (mean, invstd, scale, shift); updates running stats in place
 std::vector<Tensor> bn_finalize(const Tensor& stats_in, int64_t P, const Tensor& gamma, const Tensor& beta,
                                 const c10::optional<Tensor>& running_mean, const c10::optional<Tensor>& running_var,
-                                double momentum, double eps) {
+                                double momentum, double eps, bool reset_stats) {
     CHECK_F32(stats_in); CHECK_F32(gamma); CHECK_F32(beta);
     TORCH_CHECK(stats_in.dim() == 3 && stats_in.size(1) == 2, "bn_finalize: stats must be [rows,2,C]");
     const int64_t C = stats_in.size(2);
@@ -144,7 +162,8 @@ std::vector<Tensor> bn_finalize(const Tensor& stats_in, int64_t P, const Tensor&
         const int chunk = 64;
         Tensor folded = torch::empty({(rows + chunk - 1) / chunk, 2, C}, stats.options());
         dpa::fold_rows(stats.data_ptr<float>(), rows, 2 * C, chunk, folded.data_ptr<float>(), cur_stream());
-        stats = folded; rows = folded.size(0);
+        if (reset_stats) stats_in.zero_();
+        stats = folded; rows = folded.size(0); reset_stats = false;
     }
     Tensor out = torch::empty({4, C}, stats.options());
     float* rm = nullptr; float* rv = nullptr;
@@ -155,7 +174,7 @@ std::vector<Tensor> bn_finalize(const Tensor& stats_in, int64_t P, const Tensor&
     }
     float* o = out.data_ptr<float>();
     dpa::bn_finalize(stats.data_ptr<float>(), rows, P, C, gamma.data_ptr<float>(), beta.data_ptr<float>(), rm, rv,
-                     (float)momentum, (float)eps, o, o + C, o + 2 * C, o + 3 * C, cur_stream());
+                     (float)momentum, (float)eps, o, o + C, o + 2 * C, o + 3 * C, reset_stats ? 1 : 0, cur_stream());
     return {out[0], out[1], out[2], out[3]};
 }
 
@@ -177,7 +196,8 @@ Tensor bn_apply(const Tensor& x, const c10::optional<Tensor>& residual, const Te
 
 // returns (dx, dres or undefined, dgamma, dbeta)
 std::vector<Tensor> bn_backward(const Tensor& dy, const Tensor& y, const Tensor& x, const Tensor& gamma, const Tensor& mean,
-                                const Tensor& invstd, bool relu, bool want_dres) {
+                                const Tensor& invstd, bool relu, bool want_dres, const c10::optional<Tensor>& dgamma_acc,
+                                const c10::optional<Tensor>& dbeta_acc) {
     CHECK_BF16(dy); CHECK_BF16(y); CHECK_BF16(x); CHECK_F32(gamma); CHECK_F32(mean); CHECK_F32(invstd);
     const int64_t C = x.size(-1), P = x.numel() / C;
     TORCH_CHECK(dy.numel() == x.numel() && y.numel() == x.numel(), "bn_backward: shape mismatch");
@@ -196,8 +216,14 @@ std::vector<Tensor> bn_backward(const Tensor& dy, const Tensor& y, const Tensor&
     }
     Tensor co = torch::empty({5, C}, fopt);  // dgamma, dbeta, A, B, C0
     float* o = co.data_ptr<float>();
+    float* dg = o; float* db = o + C; int accumulate = 0;
+    if (dgamma_acc.has_value() && dgamma_acc->defined()) {     // add straight into the flat gradient buffer
+        CHECK_F32((*dgamma_acc)); CHECK_F32((*dbeta_acc));
+        TORCH_CHECK(dgamma_acc->numel() == C && dbeta_acc->numel() == C, "bn_backward: accumulate targets");
+        dg = dgamma_acc->data_ptr<float>(); db = dbeta_acc->data_ptr<float>(); accumulate = 1;
+    }
     dpa::bn_bwd_finalize(stats.data_ptr<float>(), rows, P, C, gamma.data_ptr<float>(), mean.data_ptr<float>(),
-                         invstd.data_ptr<float>(), o, o + C, o + 2 * C, o + 3 * C, o + 4 * C, cur_stream());
+                         invstd.data_ptr<float>(), dg, db, accumulate, o + 2 * C, o + 3 * C, o + 4 * C, cur_stream());
     Tensor dx = torch::empty_like(x);
     Tensor dres;
     if (want_dres) dres = torch::empty_like(x);

@@ -14,9 +14,18 @@
 // layers).  K step 32.  Register-staged double-buffered LDS (issue-early /
 // write-late, one barrier per K step); LDS tiles XOR-swizzled so the ds_read_b128
 // fragment reads are bank-conflict free.  Epilogue goes through LDS so that global
-// stores are 16 B per lane over full NHWC rows, and optionally emits per-channel
-// (sum, sum of squares) partials for a following BatchNorm, which removes one
-// full read of the activation tensor per layer.
+// stores are 16 B per lane over full NHWC rows.  Optional fused epilogue work:
+//   * per-channel (sum, sum of squares) of the output for a following BatchNorm, added
+//     with fp32 atomics into a small replicated buffer (removes one full read of the
+//     activation tensor per layer);
+//   * `addend`: y = conv(...) + addend, which folds the residual-branch gradient add of
+//     a bottleneck block into the dgrad kernel.
+//
+// MODE 0 fprop; MODE 1 dgrad at stride 1; MODE 2 dgrad at stride > 1, decomposed by
+// output-pixel parity class: a pixel (h, w) only receives taps r = (h + pad) mod stride
+// (+ k*stride), so each class is a dense small convolution and no MFMA work is spent on
+// structurally-zero taps (a masked stride-2 3x3 dgrad would waste 75 % of it; a strided
+// 1x1 dgrad is one dense GEMM on a quarter of the pixels plus zero fill).
 #include "common.h"
 #include "kernels.h"
 
@@ -32,7 +41,7 @@ __device__ __forceinline__ int swz4(int row) {  // conflict-free chunk swizzle f
 }
 
 template <int WP, int WC, int MODE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c, long M, int Kg) {
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c, long M_all, int Kg_all) {
     constexpr int BP = WP * 64, BC = WC * 64;
     constexpr int XR = BP * CHUNKS / 256;  // x rows per thread
     constexpr int WR = BC * CHUNKS / 256;  // w rows per thread
@@ -45,6 +54,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave / WC, wc = wave % WC;
 
+    // ---- geometry of this launch / parity class ----
+    // pixel grid of the GEMM rows: [N][PH][PW]; MODE 2 walks every `stride`-th output pixel
+    int PH = a.Ho, PW = a.Wo, ph0 = 0, pw0 = 0;       // class origin in the output image
+    int r0 = 0, s0 = 0, nr = a.R, ns = a.S, tstep = 1; // taps r = r0 + tstep * kr, kr < nr
+    if (MODE == 2) {
+        const int st = a.stride;
+        ph0 = blockIdx.y / st; pw0 = blockIdx.y % st;
+        PH = (a.Ho - ph0 + st - 1) / st; PW = (a.Wo - pw0 + st - 1) / st;
+        r0 = (ph0 + a.pad) % st; s0 = (pw0 + a.pad) % st;
+        nr = r0 < a.R ? (a.R - r0 + st - 1) / st : 0;
+        ns = s0 < a.S ? (a.S - s0 + st - 1) / st : 0;
+        tstep = st;
+    }
+    const long M = (MODE == 2) ? (long)a.N * PH * PW : M_all;
+    const int Kg = (MODE == 2) ? nr * ns * a.C : Kg_all;
+
     // XCD-aware remap: blocks that share an XCD (bid % 8) get a contiguous range of
     // tiles, so the channel tiles of one pixel tile hit the same L2.  Bijective.
     int lid;
@@ -55,6 +80,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c
     }
     const int tile_c = lid % tiles_c, tile_p = lid / tiles_c;
     const long m0 = (long)tile_p * BP;
+    if (m0 >= M) return;                   // MODE 2: classes differ in size; block-uniform exit
     const int c0 = tile_c * BC;
 
     const unsigned short* __restrict__ xg = (const unsigned short*)a.x;
@@ -66,25 +92,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c
     int hi0[XR], wi0[XR];
     int nb[XR];
     bool rvalid[XR];
-    const int HoWo = a.Ho * a.Wo;
+    const int PHW = PH * PW;
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
         long m = m0 + lrow + i * 64;
         rvalid[i] = m < M;
         long mm = rvalid[i] ? m : 0;
-        int n = (int)(mm / HoWo);
-        int rem = (int)(mm - (long)n * HoWo);
-        int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        int n = (int)(mm / PHW);
+        int rem = (int)(mm - (long)n * PHW);
+        int ho = rem / PW, wo = rem - ho * PW;
         nb[i] = n * a.H * a.W;
-        if (MODE == 0) { hi0[i] = ho * a.stride - a.pad; wi0[i] = wo * a.stride - a.pad; }
-        else           { hi0[i] = ho + a.pad;            wi0[i] = wo + a.pad; }
+        if (MODE == 0)      { hi0[i] = ho * a.stride - a.pad; wi0[i] = wo * a.stride - a.pad; }
+        else if (MODE == 1) { hi0[i] = ho + a.pad;            wi0[i] = wo + a.pad; }
+        else                { hi0[i] = (ho * a.stride + ph0 + a.pad - r0) / a.stride;   // exact division
+                              wi0[i] = (wo * a.stride + pw0 + a.pad - s0) / a.stride; }
     }
-    int kr = 0, ks = 0, kc = chunk * 8;  // (r, s, c) of this thread's chunk
-    while (kc >= a.C) { kc -= a.C; if (++ks == a.S) { ks = 0; ++kr; } }
+    int kr = 0, ks = 0, kc = chunk * 8;  // (tap row, tap col, channel) of this thread's chunk
+    while (kc >= a.C) { kc -= a.C; if (++ks == ns) { ks = 0; ++kr; } }
 
     u32x4 xreg[XR], wreg[WR];
     unsigned okmask = 0;   // bit i: x row i valid, bit 8+i: w row i valid (tile in flight)
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const int KgW = a.R * a.S * a.C;       // row pitch of the filter matrix
 
     // Branch-free gather: every lane ALWAYS issues its 16-byte loads (an invalid lane reads
     // the tensor's first bytes, which stay cached) and the value is zeroed by a select when
@@ -92,38 +121,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c
     // sits behind the compute.  (A predicated `if (ok) load` makes hipcc wait vmcnt(0) right
     // behind each load: four serialised HBM round trips per K step.)  Offsets are 32-bit
     // element indices (host checks numel < 2^31) so the address math is a few VALU ops.
-#define DPA_LOAD_TILE(KT)                                                                        \
+#define DPA_LOAD_TILE()                                                                          \
     {                                                                                            \
-        const bool kok = kr < a.R;                                                               \
+        const bool kok = kr < nr;                                                                \
         okmask = 0;                                                                              \
         _Pragma("unroll") for (int i = 0; i < XR; ++i) {                                         \
             int hi, wi;                                                                          \
-            bool ok = rvalid[i] && kok;                                                          \
-            if (MODE == 0) {                                                                     \
-                hi = hi0[i] + kr; wi = wi0[i] + ks;                                              \
-            } else {                                                                             \
-                const int th = hi0[i] - kr, tw = wi0[i] - ks;                                    \
-                if (a.stride == 1) { hi = th; wi = tw; }                                         \
-                else {                                                                           \
-                    hi = th / a.stride; wi = tw / a.stride;                                      \
-                    ok = ok && th >= 0 && tw >= 0 && (hi * a.stride == th) && (wi * a.stride == tw); \
-                }                                                                                \
-            }                                                                                    \
-            ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;             \
+            if (MODE == 0) { hi = hi0[i] + kr; wi = wi0[i] + ks; }                               \
+            else           { hi = hi0[i] - kr; wi = wi0[i] - ks; }                               \
+            const bool ok = rvalid[i] && kok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W; \
             const unsigned off = ok ? (unsigned)((nb[i] + hi * a.W + wi) * a.C + kc) : 0u;       \
             xreg[i] = *(const u32x4*)(xg + off);                                                 \
             okmask |= (ok ? 1u : 0u) << i;                                                       \
         }                                                                                        \
-        const int k = (KT) * BK + chunk * 8;                                                     \
+        const int wk = ((r0 + tstep * kr) * a.S + (s0 + tstep * ks)) * a.C + kc;                 \
         _Pragma("unroll") for (int i = 0; i < WR; ++i) {                                         \
             const int co = c0 + lrow + i * 64;                                                   \
-            const bool ok = co < a.K && k < Kg;                                                  \
-            const unsigned off = ok ? (unsigned)(co * Kg + k) : 0u;                              \
+            const bool ok = co < a.K && kok;                                                     \
+            const unsigned off = ok ? (unsigned)(co * KgW + wk) : 0u;                            \
             wreg[i] = *(const u32x4*)(wg + off);                                                 \
             okmask |= (ok ? 1u : 0u) << (8 + i);                                                 \
         }                                                                                        \
         kc += BK;                                                                                \
-        while (kc >= a.C) { kc -= a.C; if (++ks == a.S) { ks = 0; ++kr; } }                      \
+        while (kc >= a.C) { kc -= a.C; if (++ks == ns) { ks = 0; ++kr; } }                       \
     }
 
     const int wsw = chunk ^ swz4(lrow);  // (row>>2)&3 is the same for lrow + 64*i
@@ -147,12 +167,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c
     const int frow = lane & 15;
     const int fsw = (lane >> 4) ^ swz4(frow);
 
-    DPA_LOAD_TILE(0)
-    DPA_STORE_TILE(0)
+    if (nk > 0) {
+        DPA_LOAD_TILE()
+        DPA_STORE_TILE(0)
+    }
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) DPA_LOAD_TILE(kt + 1)
+        if (kt + 1 < nk) DPA_LOAD_TILE()
         const unsigned char* xs = smem + cur * STAGE_BYTES;
         const unsigned char* ws = xs + BP * BK * 2;
         bf16x8 af[4], bfr[4];
@@ -179,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c
         float b[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.bias != nullptr) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (c0 + col + r < a.K) b[r] = a.bias[c0 + col + r];
+            for (int r = 0; r < 4; ++r) b[r] = a.bias[min(c0 + col + r, a.K - 1)];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -200,7 +222,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c
     }
     __syncthreads();
 
-    // ---- optional BatchNorm partial statistics: one (sum, sumsq) per channel per 64 rows ----
+    // ---- optional BatchNorm statistics: per-channel (sum, sumsq) of the bf16-rounded tile,
+    //      added into replica (tile_p mod stats_rows) of a zero-initialised [rows][2][K] buffer.
+    //      One wave-instruction adds 64 consecutive floats (256 contiguous bytes). ----
     if (a.stats != nullptr) {
         const int col = tid % BC, grp = tid / BC;  // BC * WP == 256
         float s = 0.f, q = 0.f;
@@ -209,15 +233,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c
             float v = bf16_to_float(cs[(grp * 64 + r) * CS + col]);
             s += v; q += v * v;
         }
-        const long srow = m0 / 64 + grp;
-        if (srow * 64 < M && c0 + col < a.K) {
-            a.stats[(srow * 2 + 0) * a.K + c0 + col] = s;
-            a.stats[(srow * 2 + 1) * a.K + c0 + col] = q;
+        if (c0 + col < a.K) {
+            float* dst = a.stats + (long)(tile_p % a.stats_rows) * 2 * a.K + c0 + col;
+            atomicAdd(dst, s);
+            atomicAdd(dst + a.K, q);
         }
     }
 
     // ---- coalesced write-out: 16 B per lane over full output rows ----
     unsigned short* yg = (unsigned short*)a.y;
+    const unsigned short* addg = (const unsigned short*)a.addend;
     constexpr int CPR = BC / 8;        // chunks per row
     constexpr int RPP = 256 / CPR;     // rows per pass
     const int och = tid % CPR, orow = tid / CPR;
@@ -227,8 +252,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c
         const long m = m0 + row;
         const int co = c0 + och * 8;
         if (m < M && co < a.K) {
+            long orow_g = m;           // output pixel index in [N][Ho][Wo]
+            if (MODE == 2) {
+                const int n = (int)(m / PHW);
+                const int rem = (int)(m - (long)n * PHW);
+                const int hh = rem / PW, ww = rem - hh * PW;
+                orow_g = ((long)n * a.Ho + hh * a.stride + ph0) * a.Wo + ww * a.stride + pw0;
+            }
             uint4 v = *(const uint4*)(cs + row * CS + och * 8);
-            *(uint4*)(yg + m * a.K + co) = v;
+            if (addg != nullptr) {
+                const uint4 ad = *(const uint4*)(addg + orow_g * a.K + co);
+                float f[8], g[8];
+                unpack8(v, f); unpack8(ad, g);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] += g[j];
+                v = pack8(f);
+            }
+            *(uint4*)(yg + orow_g * a.K + co) = v;
         }
     }
 }
@@ -240,18 +280,25 @@ template <int WP, int WC>
 void launch(const ConvArgs& a, hipStream_t st) {
     const long M = (long)a.N * a.Ho * a.Wo;
     const int Kg = a.R * a.S * a.C;
-    const int tiles_p = (int)((M + WP * 64 - 1) / (WP * 64));
     const int tiles_c = (a.K + WC * 64 - 1) / (WC * 64);
-    dim3 grid(tiles_p * tiles_c), block(256);
-    if (a.mode == 0)
-        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 0>), grid, block, 0, st, a, tiles_c, M, Kg);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 1>), grid, block, 0, st, a, tiles_c, M, Kg);
+    dim3 block(256);
+    if (a.mode == 0) {
+        const int tiles_p = (int)((M + WP * 64 - 1) / (WP * 64));
+        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 0>), dim3(tiles_p * tiles_c), block, 0, st, a, tiles_c, M, Kg);
+    } else if (a.stride == 1) {
+        const int tiles_p = (int)((M + WP * 64 - 1) / (WP * 64));
+        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 1>), dim3(tiles_p * tiles_c), block, 0, st, a, tiles_c, M, Kg);
+    } else {
+        const int st_ = a.stride;
+        const long mc = (long)a.N * ((a.Ho + st_ - 1) / st_) * ((a.Wo + st_ - 1) / st_);   // largest parity class
+        const int tiles_p = (int)((mc + WP * 64 - 1) / (WP * 64));
+        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 2>), dim3(tiles_p * tiles_c, st_ * st_), block, 0, st, a, tiles_c, M, Kg);
+    }
 }
 
 }  // namespace
 
-int conv_stats_rows(long M) { return (int)((M + 63) / 64); }
+int conv_stats_rows(long M) { (void)M; return 32; }
 
 void conv_igemm(const ConvArgs& a, hipStream_t st) {
     if (a.K <= 64) launch<4, 1>(a, st);

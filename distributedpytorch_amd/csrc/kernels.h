@@ -19,14 +19,17 @@ struct ConvArgs {
     const void* w;      // bf16 [K, R, S, C]
     void* y;            // bf16 [N, Ho, Wo, K]
     const float* bias;  // fp32 [K] or nullptr
-    float* stats;       // fp32 [ceil(M/64)][2][K] partial (sum, sumsq) per 64 output rows, or nullptr
+    float* stats;       // fp32 [stats_rows][2][K]: (sum, sumsq) per channel are ADDED (atomics) into replica
+                        // (pixel tile mod stats_rows); must be zero before the launch; or nullptr
+    int stats_rows;
+    const void* addend; // bf16 [N, Ho, Wo, K] added to the output (residual-gradient fusion), or nullptr
     int N, H, W, C, K, R, S, Ho, Wo;
     int stride, pad;
     int mode;           // 0 fprop, 1 dgrad
     int act;            // 0 none, 1 relu, 2 gelu(tanh)
 };
 void conv_igemm(const ConvArgs& a, hipStream_t st);
-int conv_stats_rows(long M);  // rows of the stats partial buffer for M output pixels
+int conv_stats_rows(long M);  // replica rows of the stats buffer
 
 // wgrad: dw[k,r,s,c] += sum_{n,ho,wo} dy[n,ho,wo,k] * x[n, ho*stride-pad+r, wo*stride-pad+s, c]
 // dw is fp32 and is accumulated into with float atomics (split over the pixel axis).
@@ -51,9 +54,9 @@ void bn_stats(const void* x, float* stats, long P, int C, hipStream_t st);
 // out[o][:] = sum of in rows [o*chunk, (o+1)*chunk); cols floats per row (fold a tall partial buffer)
 void fold_rows(const float* in, int rows, int cols, int chunk, float* out, hipStream_t st);
 // reduce partials, produce per-channel scale/shift + saved mean/invstd, update running stats
-void bn_finalize(const float* stats, int rows, long P, int C, const float* gamma, const float* beta,
+void bn_finalize(float* stats, int rows, long P, int C, const float* gamma, const float* beta,
                  float* running_mean, float* running_var, float momentum, float eps,
-                 float* mean, float* invstd, float* scale, float* shift, hipStream_t st);
+                 float* mean, float* invstd, float* scale, float* shift, int reset_stats, hipStream_t st);
 // y = act(x*scale[c] + shift[c] (+ residual))
 void bn_apply(const void* x, const void* residual, void* y, const float* scale, const float* shift,
               long P, int C, int relu, hipStream_t st);
@@ -62,8 +65,8 @@ void bn_bwd_stats(const void* dy, const void* y, const void* x, const float* mea
                   float* stats, long P, int C, int relu, hipStream_t st);
 // reduce partials -> dgamma, dbeta (accumulate=0: overwrite) and coefficients A,B,C0 with dx = A*g + B*x + C0
 void bn_bwd_finalize(const float* stats, int rows, long P, int C, const float* gamma, const float* mean,
-                     const float* invstd, float* dgamma, float* dbeta, float* coefA, float* coefB, float* coefC,
-                     hipStream_t st);
+                     const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coefA, float* coefB,
+                     float* coefC, hipStream_t st);
 // backward pass 2: dx = A*g + B*x + C0 ; optionally dres = g
 void bn_bwd_apply(const void* dy, const void* y, const void* x, const float* coefA, const float* coefB,
                   const float* coefC, void* dx, void* dres, long P, int C, int relu, hipStream_t st);

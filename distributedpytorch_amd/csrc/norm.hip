@@ -60,17 +60,21 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const unsigned short* __r
     }, stats, P, C, rpb);
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int rows, long P, int C,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(float* __restrict__ stats, int rows, long P, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* running_mean, float* running_var, float momentum, float eps,
                                                           float* __restrict__ mean, float* __restrict__ invstd,
-                                                          float* __restrict__ scale, float* __restrict__ shift) {
+                                                          float* __restrict__ scale, float* __restrict__ shift, int reset) {
     // block = 64 channels x 4 row lanes
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     __shared__ double red[2][4][64];
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int r = rl; r < rows; r += 4) { s += stats[((long)r * 2) * C + c]; q += stats[((long)r * 2 + 1) * C + c]; }
+        for (int r = rl; r < rows; r += 4) {
+            float* ps = stats + ((long)r * 2) * C + c;
+            s += ps[0]; q += ps[C];
+            if (reset) { ps[0] = 0.f; ps[C] = 0.f; }   // each (row, channel) is read by exactly one thread
+        }
     red[0][rl][threadIdx.x & 63] = s; red[1][rl][threadIdx.x & 63] = q;
     __syncthreads();
     if (rl == 0 && c < C) {
@@ -143,8 +147,9 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const unsigned short*
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ stats, int rows, long P, int C,
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, float* __restrict__ cA,
-                                                              float* __restrict__ cB, float* __restrict__ cC) {
+                                                              float* __restrict__ dbeta, int accumulate,
+                                                              float* __restrict__ cA, float* __restrict__ cB,
+                                                              float* __restrict__ cC) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     __shared__ double red[2][4][64];
     double s = 0.0, q = 0.0;
@@ -156,7 +161,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
         const int l = threadIdx.x & 63;
         s = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];   // sum g       = dbeta
         q = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];   // sum g*xhat  = dgamma
-        dbeta[c] = (float)s; dgamma[c] = (float)q;
+        if (accumulate) { dbeta[c] += (float)s; dgamma[c] += (float)q; }
+        else { dbeta[c] = (float)s; dgamma[c] = (float)q; }
         const double g = gamma[c], is = invstd[c], m = mean[c], invP = 1.0 / (double)P;
         // dx = g*is*(gy - s/P - xhat*q/P),  xhat = (x-m)*is
         cA[c] = (float)(g * is);
@@ -222,11 +228,11 @@ void bn_stats(const void* x, float* stats, long P, int C, hipStream_t st) {
     hipLaunchKernelGGL(bn_stats_kernel, dim3(bn_stats_rows(P)), dim3(256), 0, st, (const unsigned short*)x, stats, P, C, rows_per_block(P));
 }
 
-void bn_finalize(const float* stats, int rows, long P, int C, const float* gamma, const float* beta,
+void bn_finalize(float* stats, int rows, long P, int C, const float* gamma, const float* beta,
                  float* running_mean, float* running_var, float momentum, float eps,
-                 float* mean, float* invstd, float* scale, float* shift, hipStream_t st) {
+                 float* mean, float* invstd, float* scale, float* shift, int reset_stats, hipStream_t st) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, stats, rows, P, C, gamma, beta,
-                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift, reset_stats);
 }
 
 void bn_apply(const void* x, const void* residual, void* y, const float* scale, const float* shift,
@@ -254,10 +260,10 @@ void bn_bwd_stats(const void* dy, const void* y, const void* x, const float* mea
 }
 
 void bn_bwd_finalize(const float* stats, int rows, long P, int C, const float* gamma, const float* mean,
-                     const float* invstd, float* dgamma, float* dbeta, float* coefA, float* coefB, float* coefC,
-                     hipStream_t st) {
+                     const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coefA, float* coefB,
+                     float* coefC, hipStream_t st) {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, stats, rows, P, C, gamma, mean, invstd,
-                       dgamma, dbeta, coefA, coefB, coefC);
+                       dgamma, dbeta, accumulate, coefA, coefB, coefC);
 }
 
 void bn_bwd_apply(const void* dy, const void* y, const void* x, const float* coefA, const float* coefB,

@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..nn import Conv2d, BatchNorm2d, Linear, conv_bn
+from ..ops import block as _block
 
 
 class Bottleneck(nn.Module):
@@ -35,6 +36,8 @@ class Bottleneck(nn.Module):
             self.downsample = None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if _block.can_fuse(self, x):
+            return _block.bottleneck(self, x)      # one autograd node, hand-scheduled backward
         identity = x
         if self.downsample is not None:
             identity = conv_bn(self.downsample[0], self.downsample[1], x, relu=False)

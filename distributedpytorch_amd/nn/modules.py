@@ -34,8 +34,9 @@ class Conv2d(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
         self.weight_lp: Optional[torch.Tensor] = None
 
-    def forward(self, x: torch.Tensor, want_stats: bool = False):
-        y, stats = ops.conv2d_nhwc(x, self.weight, self.weight_lp, self.bias, self.stride, self.padding, want_stats)
+    def forward(self, x: torch.Tensor, want_stats: bool = False, stats_buf=None):
+        y, stats = ops.conv2d_nhwc(x, self.weight, self.weight_lp, self.bias, self.stride, self.padding, want_stats,
+                                   stats_buf)
         return (y, stats) if want_stats else y
 
     def extra_repr(self):
@@ -55,17 +56,29 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x, stats=None, relu: bool = False, residual=None):
+        self._stats_buf = None
+
+    STATS_ROWS = 32     # replicas of the (sum, sumsq) accumulator the conv epilogue adds into
+
+    def stats_buffer(self, device) -> torch.Tensor:
+        """Persistent zeroed ``[rows,2,C]`` fp32 accumulator for the producing conv's epilogue;
+        the finalize kernel re-zeroes it after reading, so it is allocated exactly once."""
+        if self._stats_buf is None or self._stats_buf.device != device:
+            self._stats_buf = torch.zeros(self.STATS_ROWS, 2, self.num_features, dtype=torch.float32, device=device)
+        return self._stats_buf
+
+    def forward(self, x, stats=None, relu: bool = False, residual=None, reset_stats: bool = False):
         return ops.batch_norm_nhwc(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                                   self.momentum, self.eps, relu=relu, residual=residual, stats=stats)
+                                   self.momentum, self.eps, relu=relu, residual=residual, stats=stats,
+                                   reset_stats=reset_stats)
 
 
 def conv_bn(conv: Conv2d, bn: BatchNorm2d, x, relu: bool, residual=None):
     """conv -> BN (-> +residual) (-> ReLU); on the GPU the BN statistics come from the conv epilogue."""
     fuse = x.is_cuda and bn.training
     if fuse:
-        y, stats = conv(x, want_stats=True)
-        return bn(y, stats=stats, relu=relu, residual=residual)
+        y, stats = conv(x, want_stats=True, stats_buf=bn.stats_buffer(x.device))
+        return bn(y, stats=stats, relu=relu, residual=residual, reset_stats=True)
     return bn(conv(x), relu=relu, residual=residual)
 
 

@@ -32,10 +32,10 @@ def _lp(weight: torch.Tensor, weight_lp: Optional[torch.Tensor]) -> torch.Tensor
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, weight_lp, bias, stride, pad, want_stats, act, wshape):
+    def forward(ctx, x, weight, weight_lp, bias, stride, pad, want_stats, act, wshape, stats_buf=None):
         C = _ext.load()
         w = _lp(weight, weight_lp).view(wshape)   # KRSC view (a Linear weight [out,in] is K,1,1,C)
-        outs = C.conv_fprop(x, w, bias, stride, pad, act, want_stats)
+        outs = C.conv_fprop(x, w, bias, stride, pad, act, want_stats, stats_buf)
         ctx.save_for_backward(x, w)
         ctx.weight = weight
         ctx.bias = bias
@@ -54,7 +54,7 @@ class _ConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = C.conv_dgrad(dy, C.transpose_filter(w), x.shape[1], x.shape[2], stride, pad)
+            dx = C.conv_dgrad(dy, C.transpose_filter(w), x.shape[1], x.shape[2], stride, pad, None)
         weight = ctx.weight
         if weight.requires_grad:
             tgt = _sink.target(weight)
@@ -73,18 +73,21 @@ class _ConvFn(torch.autograd.Function):
             else:
                 db = torch.zeros(bias.shape, dtype=torch.float32, device=bias.device)
                 C.colsum(dy, db)
-        return dx, dw, None, db, None, None, None, None, None
+        return dx, dw, None, db, None, None, None, None, None, None
 
 
 def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, weight_lp: Optional[torch.Tensor] = None,
-                bias: Optional[torch.Tensor] = None, stride: int = 1, padding: int = 0, want_stats: bool = False):
+                bias: Optional[torch.Tensor] = None, stride: int = 1, padding: int = 0, want_stats: bool = False,
+                stats_buf: Optional[torch.Tensor] = None):
     """``x [N,H,W,C]`` * ``weight [K,R,S,C]`` -> ``y [N,Ho,Wo,K]``.
 
     Returns ``(y, stats)``; ``stats`` holds per-channel (sum, sumsq) partials of ``y``
-    from the GEMM epilogue when ``want_stats`` (GPU only), else None.
+    from the GEMM epilogue when ``want_stats`` (GPU only), else None.  ``stats_buf`` is an
+    optional persistent zero-initialised ``[rows,2,K]`` buffer to accumulate them into (the
+    BatchNorm finalize kernel re-zeroes it), which avoids one allocation + memset per layer.
     """
     if _ext.use_hip(x):
-        return _ConvFn.apply(x, weight, weight_lp, bias, stride, padding, want_stats, 0, tuple(weight.shape))
+        return _ConvFn.apply(x, weight, weight_lp, bias, stride, padding, want_stats, 0, tuple(weight.shape), stats_buf)
     y = F.conv2d(x.permute(0, 3, 1, 2), weight.to(x.dtype).permute(0, 3, 1, 2),
                  None if bias is None else bias.to(x.dtype), stride=stride, padding=padding)
     return y.permute(0, 2, 3, 1).contiguous(), None

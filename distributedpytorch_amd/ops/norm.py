@@ -29,13 +29,14 @@ def _grad_out(param, value):
 
 class _BNTrainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps):
+    def forward(ctx, x, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, reset_stats):
         C = _ext.load()
         P = x.numel() // x.shape[-1]
         if stats is None:
             stats = C.bn_stats(x)
+            reset_stats = False
         mean, invstd, scale, shift = C.bn_finalize(stats, P, gamma.detach(), beta.detach(), running_mean, running_var,
-                                                   momentum, eps)
+                                                   momentum, eps, reset_stats)
         y = C.bn_apply(x, residual, scale, shift, relu)
         ctx.save_for_backward(x, y if relu else x, mean, invstd)
         ctx.gamma, ctx.beta = gamma, beta
@@ -48,21 +49,29 @@ class _BNTrainFn(torch.autograd.Function):
         x, y, mean, invstd = ctx.saved_tensors
         dy = dy.contiguous()
         want_res = ctx.has_res and ctx.needs_input_grad[6]
-        dx, dres, dgamma, dbeta = C.bn_backward(dy, y, x, ctx.gamma.detach(), mean, invstd, ctx.relu, want_res)
-        dg = _grad_out(ctx.gamma, dgamma) if ctx.gamma.requires_grad else None
-        db = _grad_out(ctx.beta, dbeta) if ctx.beta.requires_grad else None
-        return dx, None, dg, db, None, None, (dres if want_res else None), None, None, None
+        tg, tb = _sink.target(ctx.gamma), _sink.target(ctx.beta)
+        if tg is not None and tb is not None:       # finalize kernel adds straight into the flat gradient buffer
+            dx, dres, _, _ = C.bn_backward(dy, y, x, ctx.gamma.detach(), mean, invstd, ctx.relu, want_res, tg, tb)
+            _sink.ready(ctx.gamma); _sink.ready(ctx.beta)
+            dg = db = None
+        else:
+            dx, dres, dgamma, dbeta = C.bn_backward(dy, y, x, ctx.gamma.detach(), mean, invstd, ctx.relu, want_res, None, None)
+            dg = dgamma if ctx.gamma.requires_grad else None
+            db = dbeta if ctx.beta.requires_grad else None
+        return dx, None, dg, db, None, None, (dres if want_res else None), None, None, None, None
 
 
 def batch_norm_nhwc(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
                     running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor],
                     training: bool = True, momentum: float = 0.1, eps: float = 1e-5, relu: bool = False,
-                    residual: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    residual: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None,
+                    reset_stats: bool = False) -> torch.Tensor:
     """``relu?(BN(x) + residual?)`` over the last (channel) axis of an NHWC tensor."""
     if _ext.use_hip(x):
         C = _ext.load()
         if training:
-            return _BNTrainFn.apply(x, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps)
+            return _BNTrainFn.apply(x, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps,
+                                    reset_stats)
         # inference: fold running stats into scale/shift (cold path), apply with the same streaming kernel
         scale = (gamma.detach() * torch.rsqrt(running_var + eps)).float().contiguous()
         shift = (beta.detach() - running_mean * scale).float().contiguous()

@@ -74,10 +74,11 @@ def main():
         dy = torch.randn(N, Ho, Ho, K, device=dev).to(torch.bfloat16)
         wt = C.transpose_filter(w)
         dw = torch.zeros(K, R, R, Cin, device=dev)
+        sbuf = torch.zeros(32, 2, K, device=dev)
         flops = 2.0 * N * Ho * Ho * K * R * R * Cin
         byts = 2.0 * (x.numel() + dy.numel() + w.numel())
-        tf = timeit(lambda: C.conv_fprop(x, w, None, s, p, 0, True), a.iters)
-        td = timeit(lambda: C.conv_dgrad(dy, wt, H, H, s, p), a.iters) if name != "stem7x7" else 0.0
+        tf = timeit(lambda: C.conv_fprop(x, w, None, s, p, 0, True, sbuf), a.iters)
+        td = timeit(lambda: C.conv_dgrad(dy, wt, H, H, s, p, None), a.iters) if name != "stem7x7" else 0.0
         tw = timeit(lambda: C.conv_wgrad(x, dy, dw, s, p), a.iters)
         rows.append(dict(name=name, count=cnt, fprop_us=tf, dgrad_us=td, wgrad_us=tw, gflop=flops / 1e9))
         tot["fprop"] += tf * cnt; tot["dgrad"] += td * cnt; tot["wgrad"] += tw * cnt

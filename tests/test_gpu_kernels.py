@@ -59,7 +59,7 @@ def test_conv_fprop(case):
     N, H, W, C, K, R, s, p = case
     x = _rand_bf16(N, H, W, C, seed=1)
     w = _rand_bf16(K, R, R, C, scale=1.0 / math.sqrt(R * R * C), seed=2)
-    (y,) = _C().conv_fprop(x, w, None, s, p, 0, False)
+    (y,) = _C().conv_fprop(x, w, None, s, p, 0, False, None)
     ref = _ref_conv(x, w, s, p).permute(0, 2, 3, 1)
     assert y.shape == ref.shape
     _close(y, ref, 1e-2, 2e-2, "fprop")
@@ -70,14 +70,23 @@ def test_conv_fprop_bias_relu_and_stats():
     x = _rand_bf16(N, H, W, C, seed=3)
     w = _rand_bf16(K, 3, 3, C, scale=0.05, seed=4)
     b = torch.randn(K, device=DEV)
-    (y,) = _C().conv_fprop(x, w, b, 1, 1, 1, False)
+    (y,) = _C().conv_fprop(x, w, b, 1, 1, 1, False, None)
     ref = F.relu(_ref_conv(x, w, 1, 1) + b.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
     _close(y, ref, 1e-2, 2e-2, "bias+relu")
-    y2, stats = _C().conv_fprop(x, w, None, 1, 1, 0, True)
+    y2, stats = _C().conv_fprop(x, w, None, 1, 1, 0, True, None)
     yf = y2.float().reshape(-1, K)
     s = stats.sum(0)
     _close(s[0], yf.sum(0), 1e-3, 5e-2, "stats sum")
     _close(s[1], (yf * yf).sum(0), 1e-3, 5e-2, "stats sumsq")
+    # persistent accumulator: conv adds into it, bn_finalize(reset) re-zeroes it
+    buf = torch.zeros(32, 2, K, device=DEV)
+    _C().conv_fprop(x, w, None, 1, 1, 0, True, buf)
+    _close(buf.sum(0)[0], yf.sum(0), 1e-3, 5e-2, "stats_buf sum")
+    g, bt = torch.ones(K, device=DEV), torch.zeros(K, device=DEV)
+    mean, invstd, scale, shift = _C().bn_finalize(buf, yf.shape[0], g, bt, None, None, 0.1, 1e-5, True)
+    _close(mean, yf.mean(0), 1e-3, 1e-3, "mean from fused stats")
+    _close(invstd, 1.0 / torch.sqrt(yf.var(0, unbiased=False) + 1e-5), 1e-3, 1e-3, "invstd from fused stats")
+    assert float(buf.abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
@@ -88,11 +97,15 @@ def test_conv_dgrad(case):
     w = _rand_bf16(K, R, R, C, scale=1.0 / math.sqrt(R * R * K), seed=6)
     wt = _C().transpose_filter(w)
     assert torch.equal(wt, w.permute(3, 1, 2, 0).contiguous())
-    dx = _C().conv_dgrad(dy, wt, H, W, s, p)
+    dx = _C().conv_dgrad(dy, wt, H, W, s, p, None)
     xr = torch.zeros(N, C, H, W, requires_grad=True)
     yr = F.conv2d(xr, w.float().cpu().permute(0, 3, 1, 2), stride=s, padding=p)
     yr.backward(dy.float().cpu().permute(0, 3, 1, 2))
     _close(dx, xr.grad.permute(0, 2, 3, 1), 1e-2, 2e-2, "dgrad")
+    # fused residual-gradient add in the epilogue
+    add = _rand_bf16(N, H, W, C, seed=55)
+    dx2 = _C().conv_dgrad(dy, wt, H, W, s, p, add)
+    _close(dx2, xr.grad.permute(0, 2, 3, 1) + add.float().cpu(), 1e-2, 3e-2, "dgrad+addend")
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
