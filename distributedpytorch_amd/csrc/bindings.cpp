@@ -197,18 +197,27 @@ Tensor bn_apply(const Tensor& x, const c10::optional<Tensor>& residual, const Te
 // returns (dx, dres or undefined, dgamma, dbeta)
 std::vector<Tensor> bn_backward(const Tensor& dy, const Tensor& y, const Tensor& x, const Tensor& gamma, const Tensor& mean,
                                 const Tensor& invstd, bool relu, bool want_dres, const c10::optional<Tensor>& dgamma_acc,
-                                const c10::optional<Tensor>& dbeta_acc) {
+                                const c10::optional<Tensor>& dbeta_acc, const c10::optional<Tensor>& stats_buf) {
     CHECK_BF16(dy); CHECK_BF16(y); CHECK_BF16(x); CHECK_F32(gamma); CHECK_F32(mean); CHECK_F32(invstd);
     const int64_t C = x.size(-1), P = x.numel() / C;
     TORCH_CHECK(dy.numel() == x.numel() && y.numel() == x.numel(), "bn_backward: shape mismatch");
     TORCH_CHECK(C % 8 == 0 && C <= 2048 && gamma.numel() == C && mean.numel() == C && invstd.numel() == C, "bn_backward: channels");
     Guard g(x);
     auto fopt = x.options().dtype(at::kFloat);
-    int rows = dpa::bn_stats_rows(P);
-    Tensor stats = torch::empty({rows, 2, C}, fopt);
+    int rows; int replicas = 0; int reset = 0;
+    Tensor stats;
+    if (stats_buf.has_value() && stats_buf->defined()) {     // persistent zeroed accumulator (re-zeroed by the finalize kernel)
+        stats = *stats_buf;
+        CHECK_F32(stats);
+        TORCH_CHECK(stats.dim() == 3 && stats.size(1) == 2 && stats.size(2) == C, "bn_backward: stats_buf must be [rows,2,C]");
+        rows = stats.size(0); replicas = rows; reset = 1;
+    } else {
+        rows = dpa::bn_stats_rows(P);
+        stats = torch::empty({rows, 2, C}, fopt);
+    }
     dpa::bn_bwd_stats(dy.data_ptr(), y.data_ptr(), x.data_ptr(), mean.data_ptr<float>(), invstd.data_ptr<float>(),
-                      stats.data_ptr<float>(), P, C, relu, cur_stream());
-    if (rows > 256) {
+                      stats.data_ptr<float>(), P, C, relu, replicas, cur_stream());
+    if (replicas == 0 && rows > 256) {
         const int chunk = 64;
         Tensor folded = torch::empty({(rows + chunk - 1) / chunk, 2, C}, fopt);
         dpa::fold_rows(stats.data_ptr<float>(), rows, 2 * C, chunk, folded.data_ptr<float>(), cur_stream());
@@ -223,7 +232,7 @@ std::vector<Tensor> bn_backward(const Tensor& dy, const Tensor& y, const Tensor&
         dg = dgamma_acc->data_ptr<float>(); db = dbeta_acc->data_ptr<float>(); accumulate = 1;
     }
     dpa::bn_bwd_finalize(stats.data_ptr<float>(), rows, P, C, gamma.data_ptr<float>(), mean.data_ptr<float>(),
-                         invstd.data_ptr<float>(), dg, db, accumulate, o + 2 * C, o + 3 * C, o + 4 * C, cur_stream());
+                         invstd.data_ptr<float>(), dg, db, accumulate, o + 2 * C, o + 3 * C, o + 4 * C, reset, cur_stream());
     Tensor dx = torch::empty_like(x);
     Tensor dres;
     if (want_dres) dres = torch::empty_like(x);
@@ -332,7 +341,8 @@ Tensor softmax_ce_bwd(const Tensor& logits, const Tensor& targets, const Tensor&
 
 // ---------------------------------------------------------------- optimizer / casts
 void sgd_momentum(Tensor& p, Tensor& grad, const c10::optional<Tensor>& m, const c10::optional<Tensor>& p_lp, double lr,
-                  double mu, double wd, double grad_scale, bool zero_grad, bool nesterov) {
+                  double mu, double wd, double grad_scale, bool zero_grad, bool nesterov,
+                  const c10::optional<Tensor>& seg_ends, const c10::optional<Tensor>& seg_wd) {
     CHECK_F32(p); CHECK_F32(grad);
     const int64_t n = p.numel();
     TORCH_CHECK(grad.numel() == n, "sgd: grad size");
@@ -348,9 +358,16 @@ void sgd_momentum(Tensor& p, Tensor& grad, const c10::optional<Tensor>& m, const
         TORCH_CHECK(p_lp->scalar_type() == at::kBFloat16 && p_lp->numel() == n && ((uintptr_t)p_lp->data_ptr()) % 8 == 0, "sgd: bf16 shadow");
         lp = p_lp->data_ptr();
     }
+    const long* se = nullptr; const float* sw = nullptr; int nseg = 0;
+    if (seg_ends.has_value() && seg_ends->defined()) {
+        CHECK_I64((*seg_ends)); CHECK_F32((*seg_wd));
+        nseg = seg_ends->numel();
+        TORCH_CHECK(seg_wd->numel() == nseg && nseg >= 1, "sgd: segment table");
+        se = (const long*)seg_ends->data_ptr<int64_t>(); sw = seg_wd->data_ptr<float>();
+    }
     Guard g(p);
     dpa::sgd_momentum(p.data_ptr<float>(), grad.data_ptr<float>(), mp, lp, n, (float)lr, (float)mu, (float)wd,
-                      (float)grad_scale, zero_grad, nesterov, cur_stream());
+                      (float)grad_scale, zero_grad, nesterov, se, sw, nseg, cur_stream());
 }
 
 void adamw(Tensor& p, Tensor& grad, Tensor& m, Tensor& v, const c10::optional<Tensor>& p_lp, double lr, double b1, double b2,

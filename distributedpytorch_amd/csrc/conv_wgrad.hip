@@ -217,7 +217,9 @@ void launch(const WgradArgs& a, hipStream_t st) {
     const int tiles_n = (Kg + WN * 64 - 1) / (WN * 64);
     const int tiles = tiles_m * tiles_n;
     const int steps = (int)((P + BKP - 1) / BKP);
-    int split = 1024 / tiles;
+    // ~2 workgroups per CU: every extra split adds a full fp32 copy of dw to the atomic traffic
+    // (chip-wide float-atomic rate is ~1.3 TB/s), so do not over-split large filters.
+    int split = 512 / tiles;
     if (split < 1) split = 1;
     int max_split = steps / 8;
     if (max_split < 1) max_split = 1;

@@ -205,8 +205,18 @@ void launch_ew(const void* a, const void* b, void* y, long n, hipStream_t st) {
 template <bool LP>
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                   unsigned short* __restrict__ plp, long n4, long n, float lr, float mu,
-                                                  float wd, float gs, int zero_grad, int nesterov) {
+                                                  float wd_all, float gs, int zero_grad, int nesterov,
+                                                  const long* __restrict__ seg_ends, const float* __restrict__ seg_wd, int nseg) {
     GRID_STRIDE(i, n4) {
+        // per-segment weight decay (conv / linear weights decay, norm affine + biases do not): binary
+        // search the segment table; segments are 64-element aligned so a float4 never straddles one
+        float wd = wd_all;
+        if (nseg > 0) {
+            const long e = i * 4;
+            int lo = 0, hi = nseg - 1;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (seg_ends[mid] > e) hi = mid; else lo = mid + 1; }
+            wd = seg_wd[lo];
+        }
         float4 pv = *(float4*)(p + i * 4), gv = *(float4*)(g + i * 4);
         float4 mv = (mu != 0.f) ? *(float4*)(m + i * 4) : make_float4(0, 0, 0, 0);
         float pp[4] = {pv.x, pv.y, pv.z, pv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w};
@@ -230,6 +240,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
     // scalar tail (n % 4), handled by block 0
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const long i = n4 * 4 + threadIdx.x;
+        const float wd = nseg > 0 ? seg_wd[nseg - 1] : wd_all;
         float d = g[i] * gs + wd * p[i];
         if (mu != 0.f) { float mm = mu * m[i] + d; m[i] = mm; d = nesterov ? d + mu * mm : mm; }
         const float pp = p[i] - lr * d;
@@ -320,15 +331,16 @@ void gelu_fwd(const void* x, void* y, long n, hipStream_t st) { launch_ew<3>(x, 
 void gelu_bwd(const void* dy, const void* x, void* dx, long n, hipStream_t st) { launch_ew<4>(dy, x, dx, n, st); }
 
 void sgd_momentum(float* p, float* g, float* m, void* p_lp, long n, float lr, float mu, float wd,
-                  float grad_scale, int zero_grad, int nesterov, hipStream_t st) {
+                  float grad_scale, int zero_grad, int nesterov, const long* seg_ends, const float* seg_wd, int nseg,
+                  hipStream_t st) {
     const long n4 = n / 4;
     dim3 grid(grid_for(n4)), block(256);
     if (p_lp)
         hipLaunchKernelGGL((sgd_kernel<true>), grid, block, 0, st, p, g, m, (unsigned short*)p_lp, n4, n, lr, mu, wd,
-                           grad_scale, zero_grad, nesterov);
+                           grad_scale, zero_grad, nesterov, seg_ends, seg_wd, nseg);
     else
         hipLaunchKernelGGL((sgd_kernel<false>), grid, block, 0, st, p, g, m, (unsigned short*)nullptr, n4, n, lr, mu, wd,
-                           grad_scale, zero_grad, nesterov);
+                           grad_scale, zero_grad, nesterov, seg_ends, seg_wd, nseg);
 }
 void adamw(float* p, float* g, float* m, float* v, void* p_lp, long n, float lr, float b1, float b2, float eps,
            float wd, float grad_scale, float bc1, float bc2, int zero_grad, hipStream_t st) {

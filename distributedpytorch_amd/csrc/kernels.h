@@ -61,12 +61,13 @@ void bn_finalize(float* stats, int rows, long P, int C, const float* gamma, cons
 void bn_apply(const void* x, const void* residual, void* y, const float* scale, const float* shift,
               long P, int C, int relu, hipStream_t st);
 // backward pass 1: g = dy * (relu ? y>0 : 1); partial sums of g and g*xhat per block of rows
+// (replicas > 0: added with atomics into a zeroed [replicas][2][C] buffer instead)
 void bn_bwd_stats(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
-                  float* stats, long P, int C, int relu, hipStream_t st);
+                  float* stats, long P, int C, int relu, int replicas, hipStream_t st);
 // reduce partials -> dgamma, dbeta (accumulate=0: overwrite) and coefficients A,B,C0 with dx = A*g + B*x + C0
-void bn_bwd_finalize(const float* stats, int rows, long P, int C, const float* gamma, const float* mean,
+void bn_bwd_finalize(float* stats, int rows, long P, int C, const float* gamma, const float* mean,
                      const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coefA, float* coefB,
-                     float* coefC, hipStream_t st);
+                     float* coefC, int reset_stats, hipStream_t st);
 // backward pass 2: dx = A*g + B*x + C0 ; optionally dres = g
 void bn_bwd_apply(const void* dy, const void* y, const void* x, const float* coefA, const float* coefB,
                   const float* coefC, void* dx, void* dres, long P, int C, int relu, hipStream_t st);
@@ -96,8 +97,10 @@ void softmax_ce_bwd(const void* logits, int is_bf16, const int64_t* targets, con
 // ---------------------------------------------------------------- optimizer
 // fused SGD-momentum over a flat buffer:
 //   g' = g*grad_scale + wd*p ; m = mu*m + g' ; p -= lr*m ; p_lp = bf16(p) ; g = 0 (if zero_grad)
+// optional segment table: element i uses seg_wd[s] for the first s with seg_ends[s] > i (device arrays)
 void sgd_momentum(float* p, float* g, float* m, void* p_lp, long n, float lr, float mu, float wd,
-                  float grad_scale, int zero_grad, int nesterov, hipStream_t st);
+                  float grad_scale, int zero_grad, int nesterov, const long* seg_ends, const float* seg_wd, int nseg,
+                  hipStream_t st);
 void adamw(float* p, float* g, float* m, float* v, void* p_lp, long n, float lr, float b1, float b2, float eps,
            float wd, float grad_scale, float bc1, float bc2, int zero_grad, hipStream_t st);
 void cast_f32_to_bf16(const float* x, void* y, long n, hipStream_t st);

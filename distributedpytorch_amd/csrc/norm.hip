@@ -26,7 +26,7 @@ inline int rows_per_block(long P) {
 
 // generic two-quantity row reduction.  F(row, chunk) -> 8 x (a, b) contributions.
 template <class F>
-__device__ __forceinline__ void reduce_rows(F f, float* __restrict__ stats, long P, int C, int rpb) {
+__device__ __forceinline__ void reduce_rows(F f, float* __restrict__ stats, long P, int C, int rpb, int replicas = 0) {
     const int cpr = C / 8;                       // chunks per row
     const int ch = threadIdx.x % cpr, rl = threadIdx.x / cpr, nrl = 256 / cpr;
     __shared__ float red[2][256][9];
@@ -44,8 +44,13 @@ __device__ __forceinline__ void reduce_rows(F f, float* __restrict__ stats, long
         float ts = 0.f, tq = 0.f;
         const int cch = c >> 3, cj = c & 7;
         for (int l = 0; l < nrl; ++l) { ts += red[0][l * cpr + cch][cj]; tq += red[1][l * cpr + cch][cj]; }
-        stats[((long)blockIdx.x * 2 + 0) * C + c] = ts;
-        stats[((long)blockIdx.x * 2 + 1) * C + c] = tq;
+        if (replicas > 0) {   // accumulate into replica (block mod replicas) of a zeroed [replicas][2][C] buffer
+            float* dst = stats + ((long)(blockIdx.x % replicas) * 2) * C + c;
+            atomicAdd(dst, ts); atomicAdd(dst + C, tq);
+        } else {
+            stats[((long)blockIdx.x * 2 + 0) * C + c] = ts;
+            stats[((long)blockIdx.x * 2 + 1) * C + c] = tq;
+        }
     }
 }
 
@@ -125,7 +130,7 @@ template <bool RELU>
 __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ y,
                                                            const unsigned short* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, float* __restrict__ stats,
-                                                           long P, int C, int rpb) {
+                                                           long P, int C, int rpb, int replicas) {
     reduce_rows([&](long r, int ch, float (&s)[8], float (&q)[8]) {
         uint4 dv = *(const uint4*)(dy + r * C + ch * 8);
         uint4 xv = *(const uint4*)(x + r * C + ch * 8);
@@ -141,20 +146,24 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const unsigned short*
             const float xh = (xf[j] - mean[ch * 8 + j]) * invstd[ch * 8 + j];
             s[j] += g[j]; q[j] += g[j] * xh;
         }
-    }, stats, P, C, rpb);
+    }, stats, P, C, rpb, replicas);
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ stats, int rows, long P, int C,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict__ stats, int rows, long P, int C,
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate,
                                                               float* __restrict__ cA, float* __restrict__ cB,
-                                                              float* __restrict__ cC) {
+                                                              float* __restrict__ cC, int reset) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     __shared__ double red[2][4][64];
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int r = rl; r < rows; r += 4) { s += stats[((long)r * 2) * C + c]; q += stats[((long)r * 2 + 1) * C + c]; }
+        for (int r = rl; r < rows; r += 4) {
+            float* ps = stats + ((long)r * 2) * C + c;
+            s += ps[0]; q += ps[C];
+            if (reset) { ps[0] = 0.f; ps[C] = 0.f; }
+        }
     red[0][rl][threadIdx.x & 63] = s; red[1][rl][threadIdx.x & 63] = q;
     __syncthreads();
     if (rl == 0 && c < C) {
@@ -251,19 +260,19 @@ void bn_apply(const void* x, const void* residual, void* y, const float* scale, 
 }
 
 void bn_bwd_stats(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
-                  float* stats, long P, int C, int relu, hipStream_t st) {
+                  float* stats, long P, int C, int relu, int replicas, hipStream_t st) {
     dim3 g(bn_stats_rows(P)), b(256);
     if (relu) hipLaunchKernelGGL((bn_bwd_stats_kernel<true>), g, b, 0, st, (const unsigned short*)dy, (const unsigned short*)y,
-                                 (const unsigned short*)x, mean, invstd, stats, P, C, rows_per_block(P));
+                                 (const unsigned short*)x, mean, invstd, stats, P, C, rows_per_block(P), replicas);
     else      hipLaunchKernelGGL((bn_bwd_stats_kernel<false>), g, b, 0, st, (const unsigned short*)dy, (const unsigned short*)y,
-                                 (const unsigned short*)x, mean, invstd, stats, P, C, rows_per_block(P));
+                                 (const unsigned short*)x, mean, invstd, stats, P, C, rows_per_block(P), replicas);
 }
 
-void bn_bwd_finalize(const float* stats, int rows, long P, int C, const float* gamma, const float* mean,
+void bn_bwd_finalize(float* stats, int rows, long P, int C, const float* gamma, const float* mean,
                      const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coefA, float* coefB,
-                     float* coefC, hipStream_t st) {
+                     float* coefC, int reset_stats, hipStream_t st) {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, stats, rows, P, C, gamma, mean, invstd,
-                       dgamma, dbeta, accumulate, coefA, coefB, coefC);
+                       dgamma, dbeta, accumulate, coefA, coefB, coefC, reset_stats);
 }
 
 void bn_bwd_apply(const void* dy, const void* y, const void* x, const float* coefA, const float* coefB,

@@ -57,6 +57,7 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
         self._stats_buf = None
+        self._stats_buf_bwd = None
 
     STATS_ROWS = 32     # replicas of the (sum, sumsq) accumulator the conv epilogue adds into
 
@@ -66,6 +67,12 @@ class BatchNorm2d(nn.Module):
         if self._stats_buf is None or self._stats_buf.device != device:
             self._stats_buf = torch.zeros(self.STATS_ROWS, 2, self.num_features, dtype=torch.float32, device=device)
         return self._stats_buf
+
+    def stats_buffer_bwd(self, device) -> torch.Tensor:
+        """Same, for the two backward reductions (sum g, sum g*xhat)."""
+        if self._stats_buf_bwd is None or self._stats_buf_bwd.device != device:
+            self._stats_buf_bwd = torch.zeros(self.STATS_ROWS, 2, self.num_features, dtype=torch.float32, device=device)
+        return self._stats_buf_bwd
 
     def forward(self, x, stats=None, relu: bool = False, residual=None, reset_stats: bool = False):
         return ops.batch_norm_nhwc(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,

@@ -36,10 +36,12 @@ def _conv_bn_fwd(C, conv, bn, x, relu, residual=None):
 def _bn_bwd(C, bn, dy, y_act, x_raw, mean, invstd, relu, want_res, grads, slot):
     tg, tb = _sink.target(bn.weight), _sink.target(bn.bias)
     if tg is not None and tb is not None:
-        dx, dres, _, _ = C.bn_backward(dy, y_act, x_raw, bn.weight.detach(), mean, invstd, relu, want_res, tg, tb)
+        dx, dres, _, _ = C.bn_backward(dy, y_act, x_raw, bn.weight.detach(), mean, invstd, relu, want_res, tg, tb,
+                                       bn.stats_buffer_bwd(dy.device))
         _sink.ready(bn.weight); _sink.ready(bn.bias)
     else:
-        dx, dres, dg, db = C.bn_backward(dy, y_act, x_raw, bn.weight.detach(), mean, invstd, relu, want_res, None, None)
+        dx, dres, dg, db = C.bn_backward(dy, y_act, x_raw, bn.weight.detach(), mean, invstd, relu, want_res, None, None,
+                                         bn.stats_buffer_bwd(dy.device))
         grads[slot], grads[slot + 1] = dg, db
     return dx, dres
 

@@ -51,11 +51,11 @@ class _BNTrainFn(torch.autograd.Function):
         want_res = ctx.has_res and ctx.needs_input_grad[6]
         tg, tb = _sink.target(ctx.gamma), _sink.target(ctx.beta)
         if tg is not None and tb is not None:       # finalize kernel adds straight into the flat gradient buffer
-            dx, dres, _, _ = C.bn_backward(dy, y, x, ctx.gamma.detach(), mean, invstd, ctx.relu, want_res, tg, tb)
+            dx, dres, _, _ = C.bn_backward(dy, y, x, ctx.gamma.detach(), mean, invstd, ctx.relu, want_res, tg, tb, None)
             _sink.ready(ctx.gamma); _sink.ready(ctx.beta)
             dg = db = None
         else:
-            dx, dres, dgamma, dbeta = C.bn_backward(dy, y, x, ctx.gamma.detach(), mean, invstd, ctx.relu, want_res, None, None)
+            dx, dres, dgamma, dbeta = C.bn_backward(dy, y, x, ctx.gamma.detach(), mean, invstd, ctx.relu, want_res, None, None, None)
             dg = dgamma if ctx.gamma.requires_grad else None
             db = dbeta if ctx.beta.requires_grad else None
         return dx, None, dg, db, None, None, (dres if want_res else None), None, None, None, None

@@ -34,6 +34,7 @@ class FusedSGD:
         self.steps = 0
         # contiguous runs of the flat buffer sharing the same weight decay -> one launch each
         self.segments = self._segments(no_decay)
+        self._seg_ends = self._seg_wd = None
 
     def _segments(self, no_decay):
         f = self.flat
@@ -58,9 +59,12 @@ class FusedSGD:
         if f.device.type == "cuda":
             from .ops import _ext
             C = _ext.load()
-            for a, b, wd in self.segments:
-                C.sgd_momentum(f.master[a:b], f.grad[a:b], None if self.momentum_buf is None else self.momentum_buf[a:b],
-                               None if f.lp is None else f.lp[a:b], self.lr, self.momentum, wd, gs, zero_grad, self.nesterov)
+            if len(self.segments) > 1 and self._seg_ends is None:       # device-side weight-decay table, built once
+                self._seg_ends = torch.tensor([b for _, b, _ in self.segments], dtype=torch.int64, device=f.device)
+                self._seg_wd = torch.tensor([w for _, _, w in self.segments], dtype=torch.float32, device=f.device)
+            # ONE launch over the whole flat buffer
+            C.sgd_momentum(f.master, f.grad, self.momentum_buf, f.lp, self.lr, self.momentum, self.segments[0][2], gs,
+                           zero_grad, self.nesterov, self._seg_ends, self._seg_wd)
         else:
             for a, b, wd in self.segments:
                 p, g = f.master[a:b], f.grad[a:b]

@@ -243,7 +243,7 @@ def test_fused_sgd_matches_torch():
     p = torch.randn(n, device=DEV); g = torch.randn(n, device=DEV); m = torch.randn(n, device=DEV)
     lp = torch.empty(n, dtype=torch.bfloat16, device=DEV)
     p0, g0, m0 = p.clone(), g.clone(), m.clone()
-    _C().sgd_momentum(p, g, m, lp, 0.01, 0.5, 1e-4, 0.125, True, False)
+    _C().sgd_momentum(p, g, m, lp, 0.01, 0.5, 1e-4, 0.125, True, False, None, None)
     d = g0 * 0.125 + 1e-4 * p0
     mr = 0.5 * m0 + d
     pr = p0 - 0.01 * mr
@@ -251,6 +251,13 @@ def test_fused_sgd_matches_torch():
     _close(m, mr, 1e-6, 1e-6, "sgd m")
     _close(lp, pr, 1e-2, 1e-3, "sgd bf16 shadow")
     assert float(g.abs().max()) == 0.0
+    # per-segment weight decay table: [0, 64000) decays, the rest does not
+    p = p0.clone(); g = g0.clone(); m = m0.clone()
+    ends = torch.tensor([64000, n], dtype=torch.int64, device=DEV); wds = torch.tensor([1e-2, 0.0], device=DEV)
+    _C().sgd_momentum(p, g, m, None, 0.01, 0.5, 0.0, 1.0, False, False, ends, wds)
+    wd = torch.zeros(n, device=DEV); wd[:64000] = 1e-2
+    mr = 0.5 * m0 + (g0 + wd * p0)
+    _close(p, p0 - 0.01 * mr, 1e-6, 1e-6, "sgd segment table")
 
 
 def test_mnist_ops_match_torch():
