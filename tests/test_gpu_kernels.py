@@ -324,3 +324,26 @@ def test_layernorm_gelu_embedding():
     _close(e, er, 1e-2, 1e-2, "embedding")
     _close(wte.grad, wter.grad, 1e-3, 1e-3, "dwte")
     _close(wpe.grad, wper.grad, 1e-3, 1e-3, "dwpe")
+
+
+@pytest.mark.parametrize("B,T,H", [(1, 128, 1), (2, 256, 3), (1, 512, 2)])
+def test_causal_attention_fwd_bwd(B, T, H):
+    """Flash attention kernels vs the fp32 softmax(QK^T/sqrt(d))V oracle (ops/tfm.py CPU path)."""
+    from distributedpytorch_amd import ops
+    D = 64
+    qkv = _rand_bf16(B, T, 3 * H * D, seed=31).requires_grad_()
+    out = ops.causal_attention(qkv, H)
+    dout = _rand_bf16(B, T, H * D, seed=32)
+    out.backward(dout)
+    qr = qkv.detach().float().cpu().requires_grad_()
+    q, k, v = qr.view(B, T, 3, H, D).permute(2, 0, 3, 1, 4)
+    att = (q @ k.transpose(-2, -1)) / math.sqrt(D)
+    mask = torch.ones(T, T, dtype=torch.bool).tril()
+    att = att.masked_fill(~mask, float("-inf")).softmax(dim=-1)
+    outr = (att @ v).permute(0, 2, 1, 3).reshape(B, T, H * D)
+    outr.backward(dout.float().cpu())
+    _close(out, outr, 2e-2, 2e-2, "attention out")
+    g, gr = qkv.grad.float().cpu().view(B, T, 3, H, D), qr.grad.view(B, T, 3, H, D)
+    for i, name in enumerate(("dq", "dk", "dv")):
+        # P and dS are rounded to bf16 before the second MFMA product
+        _close(g[:, :, i], gr[:, :, i], 3e-2, 3e-2, "attention " + name)
