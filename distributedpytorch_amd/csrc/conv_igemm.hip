@@ -40,8 +40,11 @@ __device__ __forceinline__ int swz4(int row) {  // conflict-free chunk swizzle f
     return (0x78 >> (2 * ((row >> 2) & 3))) & 3;  // {0,2,3,1}[(row>>2)&3]
 }
 
-template <int WP, int WC, int MODE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c, long M_all, int Kg_all) {
+// ONE: 1x1 filter, no padding (a plain GEMM over gathered rows): no tap arithmetic in the loop.
+// Register budget: 3 waves per SIMD (<= 168 VGPRs, accumulators stay in VGPRs - no AGPR copies);
+// the 256x64 general-gather variant needs a few more and runs at 2.
+template <int WP, int WC, int MODE, bool ONE>
+__global__ __launch_bounds__(256, (WP == 4 && !ONE) ? 2 : 3) void conv_igemm_kernel(ConvArgs a, int tiles_c, long M_all, int Kg_all) {
     constexpr int BP = WP * 64, BC = WC * 64;
     constexpr int XR = BP * CHUNKS / 256;  // x rows per thread
     constexpr int WR = BC * CHUNKS / 256;  // w rows per thread
@@ -83,78 +86,90 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c
     if (m0 >= M) return;                   // MODE 2: classes differ in size; block-uniform exit
     const int c0 = tile_c * BC;
 
-    const unsigned short* __restrict__ xg = (const unsigned short*)a.x;
-    const unsigned short* __restrict__ wg = (const unsigned short*)a.w;
+    // Buffer descriptors (wave-uniform, straight from kernel arguments): 32-bit byte offsets, and a
+    // lane whose tap falls into the padding / past the tile edge is given an offset past the end
+    // of the buffer, for which the hardware returns zeros - the gather needs no branch, no select
+    // on the loaded data and no 64-bit address arithmetic.
+    const unsigned xbytes = (unsigned)a.N * a.H * a.W * a.C * 2u;
+    const int KgW = a.R * a.S * a.C;       // row pitch of the filter matrix
+    const unsigned wbytes = (unsigned)a.K * KgW * 2u;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, wbytes, 0x00020000);
 
     // ---- per-thread gather state ----
     const int chunk = tid & 3;
     const int lrow = tid >> 2;  // 0..63
     int hi0[XR], wi0[XR];
-    int nb[XR];
-    bool rvalid[XR];
+    unsigned xb[XR];            // ONE: byte offset of the row's pixel (xbytes when the row is past M); else pixel index of its image
+    unsigned wb[WR];            // byte offset of the filter row (rows past K read zeros)
     const int PHW = PH * PW;
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
         long m = m0 + lrow + i * 64;
-        rvalid[i] = m < M;
-        long mm = rvalid[i] ? m : 0;
+        const bool rv = m < M;
+        long mm = rv ? m : 0;
         int n = (int)(mm / PHW);
         int rem = (int)(mm - (long)n * PHW);
         int ho = rem / PW, wo = rem - ho * PW;
-        nb[i] = n * a.H * a.W;
         if (MODE == 0)      { hi0[i] = ho * a.stride - a.pad; wi0[i] = wo * a.stride - a.pad; }
         else if (MODE == 1) { hi0[i] = ho + a.pad;            wi0[i] = wo + a.pad; }
         else                { hi0[i] = (ho * a.stride + ph0 + a.pad - r0) / a.stride;   // exact division
                               wi0[i] = (wo * a.stride + pw0 + a.pad - s0) / a.stride; }
+        if (ONE) xb[i] = rv ? (unsigned)((n * a.H + hi0[i]) * a.W + wi0[i]) * (unsigned)a.C * 2u : xbytes;
+        else {
+            xb[i] = (unsigned)(n * a.H * a.W);   // pixel index of the image origin
+            if (!rv) hi0[i] = -(1 << 24);        // never inside the image: the row gathers zeros
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+        const int co = c0 + lrow + i * 64;
+        wb[i] = co < a.K ? (unsigned)co * (unsigned)KgW * 2u : wbytes;
     }
     int kr = 0, ks = 0, kc = chunk * 8;  // (tap row, tap col, channel) of this thread's chunk
-    while (kc >= a.C) { kc -= a.C; if (++ks == ns) { ks = 0; ++kr; } }
+    if (!ONE) while (kc >= a.C) { kc -= a.C; if (++ks == ns) { ks = 0; ++kr; } }
 
-    u32x4 xreg[XR], wreg[WR];
-    unsigned okmask = 0;   // bit i: x row i valid, bit 8+i: w row i valid (tile in flight)
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    const int KgW = a.R * a.S * a.C;       // row pitch of the filter matrix
+    // Two register sets form a ring: the loads of tile t+2 are issued before the MFMAs of tile
+    // t, and tile t+1 (issued one whole iteration earlier) is written to LDS after them, so a
+    // load has two iterations of MFMA work (times the resident blocks) to cover its latency.
+    u32x4 xr0[XR], wr0[WR], xr1[XR], wr1[WR];
 
-    // Branch-free gather: every lane ALWAYS issues its 16-byte loads (an invalid lane reads
-    // the tensor's first bytes, which stay cached) and the value is zeroed by a select when
-    // it is written to LDS - after the MFMAs of the current tile, so the wait on the loads
-    // sits behind the compute.  (A predicated `if (ok) load` makes hipcc wait vmcnt(0) right
-    // behind each load: four serialised HBM round trips per K step.)  Offsets are 32-bit
-    // element indices (host checks numel < 2^31) so the address math is a few VALU ops.
-#define DPA_LOAD_TILE()                                                                          \
+#define DPA_LOAD_TILE(XREG, WREG)                                                                \
     {                                                                                            \
-        const bool kok = kr < nr;                                                                \
-        okmask = 0;                                                                              \
-        _Pragma("unroll") for (int i = 0; i < XR; ++i) {                                         \
-            int hi, wi;                                                                          \
-            if (MODE == 0) { hi = hi0[i] + kr; wi = wi0[i] + ks; }                               \
-            else           { hi = hi0[i] - kr; wi = wi0[i] - ks; }                               \
-            const bool ok = rvalid[i] && kok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W; \
-            const unsigned off = ok ? (unsigned)((nb[i] + hi * a.W + wi) * a.C + kc) : 0u;       \
-            xreg[i] = *(const u32x4*)(xg + off);                                                 \
-            okmask |= (ok ? 1u : 0u) << i;                                                       \
+        if (ONE) {                                                                               \
+            const unsigned kadd = kc < Kg ? (unsigned)kc * 2u : xbytes;                          \
+            _Pragma("unroll") for (int i = 0; i < XR; ++i)                                       \
+                XREG[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xb[i] + kadd, 0, 0);        \
+            _Pragma("unroll") for (int i = 0; i < WR; ++i)                                       \
+                WREG[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, wb[i] + (unsigned)kc * 2u, 0, 0); \
+            kc += BK;                                                                            \
+        } else {                                                                                 \
+            const bool kok = kr < nr;                                                            \
+            _Pragma("unroll") for (int i = 0; i < XR; ++i) {                                     \
+                int hi, wi;                                                                      \
+                if (MODE == 0) { hi = hi0[i] + kr; wi = wi0[i] + ks; }                           \
+                else           { hi = hi0[i] - kr; wi = wi0[i] - ks; }                           \
+                const bool ok = kok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W; \
+                const unsigned off = ((xb[i] + (unsigned)(hi * a.W + wi)) * (unsigned)a.C + (unsigned)kc) * 2u; \
+                XREG[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? off : xbytes, 0, 0);      \
+            }                                                                                    \
+            const unsigned wk = (unsigned)(((r0 + tstep * kr) * a.S + (s0 + tstep * ks)) * a.C + kc) * 2u; \
+            _Pragma("unroll") for (int i = 0; i < WR; ++i)                                       \
+                WREG[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, kok ? wb[i] + wk : wbytes, 0, 0); \
+            kc += BK;                                                                            \
+            while (kc >= a.C) { kc -= a.C; if (++ks == ns) { ks = 0; ++kr; } }                   \
         }                                                                                        \
-        const int wk = ((r0 + tstep * kr) * a.S + (s0 + tstep * ks)) * a.C + kc;                 \
-        _Pragma("unroll") for (int i = 0; i < WR; ++i) {                                         \
-            const int co = c0 + lrow + i * 64;                                                   \
-            const bool ok = co < a.K && kok;                                                     \
-            const unsigned off = ok ? (unsigned)(co * KgW + wk) : 0u;                            \
-            wreg[i] = *(const u32x4*)(wg + off);                                                 \
-            okmask |= (ok ? 1u : 0u) << (8 + i);                                                 \
-        }                                                                                        \
-        kc += BK;                                                                                \
-        while (kc >= a.C) { kc -= a.C; if (++ks == ns) { ks = 0; ++kr; } }                       \
     }
 
     const int wsw = chunk ^ swz4(lrow);  // (row>>2)&3 is the same for lrow + 64*i
-#define DPA_STORE_TILE(BUF)                                                                      \
+#define DPA_STORE_TILE(BUF, XREG, WREG)                                                          \
     {                                                                                            \
         unsigned char* xs_ = smem + (BUF) * STAGE_BYTES;                                         \
         unsigned char* ws_ = xs_ + BP * BK * 2;                                                  \
         _Pragma("unroll") for (int i = 0; i < XR; ++i)                                           \
-            *(u32x4*)(xs_ + ((lrow + i * 64) * CHUNKS + wsw) * 16) = ((okmask >> i) & 1u) ? xreg[i] : zero4;       \
+            *(u32x4*)(xs_ + ((lrow + i * 64) * CHUNKS + wsw) * 16) = XREG[i];                    \
         _Pragma("unroll") for (int i = 0; i < WR; ++i)                                           \
-            *(u32x4*)(ws_ + ((lrow + i * 64) * CHUNKS + wsw) * 16) = ((okmask >> (8 + i)) & 1u) ? wreg[i] : zero4; \
+            *(u32x4*)(ws_ + ((lrow + i * 64) * CHUNKS + wsw) * 16) = WREG[i];                    \
     }
 
     floatx4 acc[4][4];
@@ -167,29 +182,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c
     const int frow = lane & 15;
     const int fsw = (lane >> 4) ^ swz4(frow);
 
-    if (nk > 0) {
-        DPA_LOAD_TILE()
-        DPA_STORE_TILE(0)
+#define DPA_COMPUTE(BUF)                                                                         \
+    {                                                                                            \
+        const unsigned char* xs = smem + (BUF) * STAGE_BYTES;                                    \
+        const unsigned char* ws = xs + BP * BK * 2;                                              \
+        bf16x8 af[4], bfr[4];                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+            af[i] = *(const bf16x8*)(ws + ((wc * 64 + i * 16 + frow) * CHUNKS + fsw) * 16);      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
+            bfr[j] = *(const bf16x8*)(xs + ((wp * 64 + j * 16 + frow) * CHUNKS + fsw) * 16);     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                        \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0); \
     }
+
+    // Loads past the last K tile fall outside the buffers (zeros) and their LDS image is never
+    // read, so the loop body carries no conditions.
+    DPA_LOAD_TILE(xr0, wr0)
+    DPA_LOAD_TILE(xr1, wr1)
+    DPA_STORE_TILE(0, xr0, wr0)
     __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) DPA_LOAD_TILE()
-        const unsigned char* xs = smem + cur * STAGE_BYTES;
-        const unsigned char* ws = xs + BP * BK * 2;
-        bf16x8 af[4], bfr[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(ws + ((wc * 64 + i * 16 + frow) * CHUNKS + fsw) * 16);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(xs + ((wp * 64 + j * 16 + frow) * CHUNKS + fsw) * 16);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        if (kt + 1 < nk) DPA_STORE_TILE(cur ^ 1)
+    for (int kt = 0; kt + 1 < nk; kt += 2) {
+        DPA_LOAD_TILE(xr0, wr0)            // tile kt + 2
+        __builtin_amdgcn_sched_barrier(0); // keep the loads ahead of the MFMAs and of the older tile's LDS writes
+        DPA_COMPUTE(0)                     // tile kt
+        DPA_STORE_TILE(1, xr1, wr1)        // tile kt + 1
         __syncthreads();
-        cur ^= 1;
+        DPA_LOAD_TILE(xr1, wr1)            // tile kt + 3
+        __builtin_amdgcn_sched_barrier(0);
+        DPA_COMPUTE(1)                     // tile kt + 1
+        DPA_STORE_TILE(0, xr0, wr0)        // tile kt + 2
+        __syncthreads();
+    }
+    if (nk & 1) {
+        DPA_COMPUTE(0)
+        __syncthreads();
     }
 
     // ---- epilogue: bias/activation, stage the bf16 tile in LDS ----
@@ -275,8 +302,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a, int tiles_c
 
 #undef DPA_LOAD_TILE
 #undef DPA_STORE_TILE
+#undef DPA_COMPUTE
 
-template <int WP, int WC>
+template <int WP, int WC, bool ONE>
 void launch(const ConvArgs& a, hipStream_t st) {
     const long M = (long)a.N * a.Ho * a.Wo;
     const int Kg = a.R * a.S * a.C;
@@ -284,15 +312,15 @@ void launch(const ConvArgs& a, hipStream_t st) {
     dim3 block(256);
     if (a.mode == 0) {
         const int tiles_p = (int)((M + WP * 64 - 1) / (WP * 64));
-        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 0>), dim3(tiles_p * tiles_c), block, 0, st, a, tiles_c, M, Kg);
+        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 0, ONE>), dim3(tiles_p * tiles_c), block, 0, st, a, tiles_c, M, Kg);
     } else if (a.stride == 1) {
         const int tiles_p = (int)((M + WP * 64 - 1) / (WP * 64));
-        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 1>), dim3(tiles_p * tiles_c), block, 0, st, a, tiles_c, M, Kg);
+        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 1, ONE>), dim3(tiles_p * tiles_c), block, 0, st, a, tiles_c, M, Kg);
     } else {
         const int st_ = a.stride;
         const long mc = (long)a.N * ((a.Ho + st_ - 1) / st_) * ((a.Wo + st_ - 1) / st_);   // largest parity class
         const int tiles_p = (int)((mc + WP * 64 - 1) / (WP * 64));
-        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 2>), dim3(tiles_p * tiles_c, st_ * st_), block, 0, st, a, tiles_c, M, Kg);
+        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 2, false>), dim3(tiles_p * tiles_c, st_ * st_), block, 0, st, a, tiles_c, M, Kg);
     }
 }
 
@@ -301,8 +329,10 @@ void launch(const ConvArgs& a, hipStream_t st) {
 int conv_stats_rows(long M) { (void)M; return 32; }
 
 void conv_igemm(const ConvArgs& a, hipStream_t st) {
-    if (a.K <= 64) launch<4, 1>(a, st);
-    else launch<2, 2>(a, st);
+    // 1x1 / no padding: plain GEMM gather (strided fprop included; strided dgrad goes by parity class)
+    const bool one = a.R == 1 && a.S == 1 && a.pad == 0 && (a.mode == 0 || a.stride == 1);
+    if (a.K <= 64) { if (one) launch<4, 1, true>(a, st); else launch<4, 1, false>(a, st); }
+    else           { if (one) launch<2, 2, true>(a, st); else launch<2, 2, false>(a, st); }
 }
 
 // ------------------------------------------------------------------ filter transpose

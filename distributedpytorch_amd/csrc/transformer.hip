@@ -114,13 +114,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
     }
 }
 
+// out[c] (+)= sum_r part[r][c]: a block folds 16 columns, its 16 row groups stride the partial rows
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int rows, int C,
                                                               float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += part[(long)r * C + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < C)
+        for (int r = rg; r < rows; r += 16) s += part[(long)r * C + c];
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][cl];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __restrict__ tok, const unsigned short* __restrict__ wte,
@@ -201,7 +211,7 @@ void layernorm_bwd(const void* dy, const void* x, const float* g, const float* m
 }
 
 void reduce_partials(const float* partial, int rows, int C, float* out, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, rows, C, out, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 15) / 16), dim3(256), 0, st, partial, rows, C, out, accumulate);
 }
 
 void embedding_fwd(const int64_t* tok, const void* wte, const void* wpe, void* y, long B, int T, int C, long V, hipStream_t st) {
