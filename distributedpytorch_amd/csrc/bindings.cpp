@@ -111,7 +111,8 @@ void conv_wgrad(const Tensor& x, const Tensor& dy, Tensor& dw, int64_t stride, i
     TORCH_CHECK(dy.size(0) == N && dw.size(0) == K && dw.size(3) == C, "conv_wgrad: shape mismatch");
     TORCH_CHECK((H + 2 * pad - R) / stride + 1 == Ho && (W + 2 * pad - S) / stride + 1 == Wo, "conv_wgrad: geometry mismatch");
     TORCH_CHECK(C % 8 == 0 && K % 8 == 0, "conv_wgrad: channels must be multiples of 8");
-    TORCH_CHECK(x.numel() < (1ll << 40) && dy.numel() < (1ll << 40), "conv_wgrad: tensor too large");
+    TORCH_CHECK(x.numel() < (1ll << 30) - (1ll << 24) && dy.numel() < (1ll << 30) - (1ll << 24),
+                "conv_wgrad: operands must stay below 2^31 bytes (32-bit buffer offsets)");
     Guard g(x);
     dpa::WgradArgs a{};
     a.x = x.data_ptr(); a.dy = dy.data_ptr(); a.dw = dw.data_ptr<float>();

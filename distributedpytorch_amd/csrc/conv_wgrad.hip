@@ -18,6 +18,7 @@
 // Block = 4 waves as 2x2 (128 out-channels x 128 filter columns) or 1x4
 // (64 x 256, for 64-channel layers); 32 pixels per K step; register-staged double
 // buffering with one barrier per step.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -39,8 +40,10 @@ __device__ __forceinline__ short4v tr_read(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p));
 }
 
-template <int WM, int WN>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int tiles_n, long P, int Kg, int steps_per_split) {
+// LIN: 1x1 filter, stride 1, no padding (and every Linear layer): the x operand is a plain
+// [pixel][channel] matrix like dy, so neither gather needs pixel arithmetic.
+template <int WM, int WN, bool LIN>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a, int tiles_n, int tiles, long P, int Kg, int steps_per_split) {
     constexpr int BM = WM * 64;           // out-channel rows of dw per block
     constexpr int BN = WN * 64;           // filter columns (r,s,c) per block
     constexpr int A_CPR = BM / 8;         // 16-B chunks per dy tile row
@@ -49,98 +52,133 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int tiles_
     constexpr int B_LD = BKP * B_CPR / 256;
     constexpr int A_BYTES = BKP * BM * 2, B_BYTES = BKP * BN * 2;
     constexpr int STAGE = A_BYTES + B_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    constexpr int NBUF = 3;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+    // XCD-aware bijective remap (workgroups go round-robin over the 8 XCDs): each XCD walks a
+    // contiguous range of (split, tile) pairs, tile fastest, so the output tiles that share one
+    // pixel range - and therefore the same dy / x rows - run behind the same L2.
+    int lid;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        lid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+    }
+    const int tile = lid % tiles, split_id = lid / tiles;
+    const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
     const int k0 = tile_m * BM;   // first out channel
     const int n0 = tile_n * BN;   // first filter column
 
-    const long p_begin = (long)blockIdx.y * steps_per_split * BKP;
+    const long p_begin = (long)split_id * steps_per_split * BKP;
     long p_end = p_begin + (long)steps_per_split * BKP;
     if (p_end > P) p_end = P;
     if (p_begin >= p_end) return;
     const int nsteps = (int)((p_end - p_begin + BKP - 1) / BKP);
 
-    const unsigned short* __restrict__ xg = (const unsigned short*)a.x;
-    const unsigned short* __restrict__ dyg = (const unsigned short*)a.dy;
+    // Buffer descriptors with 32-bit byte offsets; out-of-range offsets read zeros, so tile edges,
+    // image padding and the end of this block's pixel range need no branch and no select.  The
+    // dy descriptor ends at this block's last pixel: rows past p_end vanish by themselves.
+    const unsigned dybytes = (unsigned)p_end * (unsigned)a.K * 2u;
+    const unsigned xbytes = LIN ? (unsigned)p_end * (unsigned)a.C * 2u : (unsigned)a.N * a.H * a.W * a.C * 2u;
+    const __amdgpu_buffer_rsrc_t dyrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, dybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, xbytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;   // operands are < 2^31 bytes (host check): offsets >= 2^31 are always out of range
 
-    // ---- A (dy) loads: thread -> (pixel row, channel chunk) ----
+    // ---- A (dy) loads: thread -> (pixel row, channel chunk); the offset advances by a constant ----
     const int a_ch = tid % A_CPR, a_row0 = tid / A_CPR;
     constexpr int A_RSTEP = 256 / A_CPR;
-    const bool a_cok = (k0 + a_ch * 8) < a.K;
+    unsigned a_off[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        a_off[i] = ((unsigned)(p_begin + a_row0 + i * A_RSTEP) * (unsigned)a.K + (unsigned)(k0 + a_ch * 8)) * 2u;
+        if (k0 + a_ch * 8 >= a.K) a_off[i] |= OOB;
+    }
+    const unsigned a_step = (unsigned)BKP * (unsigned)a.K * 2u;
+
     // ---- B (x gather) loads: thread's filter column is fixed for the whole loop ----
     const int b_ch = tid % B_CPR, b_row0 = tid / B_CPR;
     constexpr int B_RSTEP = 256 / B_CPR;
     const int col = n0 + b_ch * 8;
     const bool b_cok = col < Kg;
-    int fr, fs, fc;
-    {
-        int cc = b_cok ? col : 0;
-        int rs = cc / a.C;
+    unsigned b_off[B_LD];                 // LIN: running byte offset
+    int pn[B_LD], pho[B_LD], pwo[B_LD];   // general: pixel state (n, ho, wo) of each row
+    int prem[B_LD];                       // general: pixels left before p_end
+    int fr = 0, fs = 0, fc = 0;
+    const unsigned b_step = (unsigned)BKP * (unsigned)a.C * 2u;
+    const int q32 = BKP / a.Wo, r32 = BKP - q32 * a.Wo;
+    if (LIN) {
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            b_off[i] = ((unsigned)(p_begin + b_row0 + i * B_RSTEP) * (unsigned)a.C + (unsigned)col) * 2u;
+            if (!b_cok) b_off[i] |= OOB;
+        }
+    } else {
+        const int cc = b_cok ? col : 0;
+        const int rs = cc / a.C;
         fc = cc - rs * a.C;
         fr = rs / a.S;
         fs = rs - fr * a.S;
+        const unsigned HoWo = (unsigned)(a.Ho * a.Wo);
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const unsigned p = (unsigned)(p_begin + b_row0 + i * B_RSTEP);   // P < 2^31 (host check)
+            const unsigned n = p / HoWo, rem = p - n * HoWo;
+            pn[i] = (int)n; pho[i] = (int)(rem / (unsigned)a.Wo); pwo[i] = (int)(rem - (unsigned)pho[i] * (unsigned)a.Wo);
+            prem[i] = b_cok ? (int)(p_end - (long)p) : 0;
+        }
     }
-    // pixel state for each of this thread's B rows: (n, ho, wo)
-    int pn[B_LD], pho[B_LD], pwo[B_LD];
-    const int HoWo = a.Ho * a.Wo;
+
+    // Three register sets + three LDS buffers: the loads of tile t+3 are issued before the MFMAs
+    // of tile t and written to LDS two iterations later, so each load has about three iterations
+    // of MFMA work (times the resident blocks) to arrive.
+    u32x4 ar0[A_LD], br0[B_LD], ar1[A_LD], br1[B_LD], ar2[A_LD], br2[B_LD];
+
+#define DPA_WG_LOAD(AREG, BREG)                                                                  \
+    {                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                       \
+            AREG[i] = __builtin_amdgcn_raw_buffer_load_b128(dyrs, a_off[i], 0, 0);               \
+            a_off[i] += a_step;                                                                  \
+        }                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < B_LD; ++i) {                                       \
+            if (LIN) {                                                                           \
+                BREG[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, b_off[i], 0, 0);            \
+                b_off[i] += b_step;                                                              \
+            } else {                                                                             \
+                const int hi = pho[i] * a.stride - a.pad + fr;                                   \
+                const int wi = pwo[i] * a.stride - a.pad + fs;                                   \
+                const bool ok = prem[i] > 0 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W; \
+                const unsigned off = ((unsigned)((pn[i] * a.H + hi) * a.W + wi) * (unsigned)a.C + (unsigned)fc) * 2u; \
+                BREG[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? off : OOB, 0, 0);      \
+                prem[i] -= BKP;                                                                  \
+                pwo[i] += r32; pho[i] += q32;                                                    \
+                if (pwo[i] >= a.Wo) { pwo[i] -= a.Wo; ++pho[i]; }                                \
+                while (pho[i] >= a.Ho) { pho[i] -= a.Ho; ++pn[i]; }                              \
+            }                                                                                    \
+        }                                                                                        \
+    }
+
+    // LDS image: [pixel][channel] rows, 64-byte granules XOR-swizzled by the pixel row
+    int a_dst[A_LD], b_dst[B_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        const int row = a_row0 + i * A_RSTEP;
+        const int ch = (((a_ch >> 2) ^ swz_key<BM * 2>(row)) << 2) | (a_ch & 3);
+        a_dst[i] = row * (BM * 2) + ch * 16;
+    }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
-        long p = p_begin + b_row0 + i * B_RSTEP;
-        int n = (int)(p / HoWo);
-        int rem = (int)(p - (long)n * HoWo);
-        pn[i] = n; pho[i] = rem / a.Wo; pwo[i] = rem - pho[i] * a.Wo;
+        const int row = b_row0 + i * B_RSTEP;
+        const int ch = (((b_ch >> 2) ^ swz_key<BN * 2>(row)) << 2) | (b_ch & 3);
+        b_dst[i] = A_BYTES + row * (BN * 2) + ch * 16;
     }
-
-    u32x4 areg[A_LD], breg[B_LD];
-    bool aok[A_LD], bok[B_LD];
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-    // Branch-free loads (see conv_igemm.hip): always load, select zero afterwards.
-    auto load_tile = [&](int st) {
-        const long pb = p_begin + (long)st * BKP;
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const long p = pb + a_row0 + i * A_RSTEP;
-            const bool ok = a_cok && p < p_end;
-            const long off = ok ? (p * a.K + k0 + a_ch * 8) : 0;
-            areg[i] = *(const u32x4*)(dyg + off);
-            aok[i] = ok;
-        }
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const long p = pb + b_row0 + i * B_RSTEP;
-            const int hi = pho[i] * a.stride - a.pad + fr;
-            const int wi = pwo[i] * a.stride - a.pad + fs;
-            const bool ok = b_cok && p < p_end && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            const long off = ok ? ((((long)pn[i] * a.H + hi) * a.W + wi) * a.C + fc) : 0;
-            breg[i] = *(const u32x4*)(xg + off);
-            bok[i] = ok;
-            // advance this row's pixel by BKP
-            pwo[i] += BKP;
-            while (pwo[i] >= a.Wo) { pwo[i] -= a.Wo; if (++pho[i] == a.Ho) { pho[i] = 0; ++pn[i]; } }
-        }
-    };
-
-    // swizzle: 64-byte granule index ^= (pixel row & 3)
-    auto store_tile = [&](int buf) {
-        unsigned char* as = smem + buf * STAGE;
-        unsigned char* bs = as + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int row = a_row0 + i * A_RSTEP;
-            const int ch = (((a_ch >> 2) ^ swz_key<BM * 2>(row)) << 2) | (a_ch & 3);
-            *(u32x4*)(as + row * (BM * 2) + ch * 16) = aok[i] ? areg[i] : zero4;
-        }
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int row = b_row0 + i * B_RSTEP;
-            const int ch = (((b_ch >> 2) ^ swz_key<BN * 2>(row)) << 2) | (b_ch & 3);
-            *(u32x4*)(bs + row * (BN * 2) + ch * 16) = bok[i] ? breg[i] : zero4;
-        }
-    };
+#define DPA_WG_STORE(BUF, AREG, BREG)                                                            \
+    {                                                                                            \
+        unsigned char* st_ = smem + (BUF) * STAGE;                                               \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i) *(u32x4*)(st_ + a_dst[i]) = AREG[i];    \
+        _Pragma("unroll") for (int i = 0; i < B_LD; ++i) *(u32x4*)(st_ + b_dst[i]) = BREG[i];    \
+    }
 
     floatx16 acc[2][2];
 #pragma unroll
@@ -155,43 +193,64 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int tiles_
     const int kofs = 8 * (gi >> 1) + tq;        // pixel row inside a 16-deep k slice (first read)
     const int cofs = (gi & 1) * 16 + 4 * tp;    // column offset inside a 32-wide tile
 
-    load_tile(0);
-    store_tile(0);
+#define DPA_WG_COMPUTE(BUF)                                                                      \
+    {                                                                                            \
+        const unsigned char* as = smem + (BUF) * STAGE;                                          \
+        const unsigned char* bs = as + A_BYTES;                                                  \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                       \
+            bf16x8 af[2], bf[2];                                                                 \
+            const int r0 = kk * 16 + kofs, r1 = r0 + 4;                                          \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                      \
+                const int c = wm * 64 + i * 32 + cofs;                                           \
+                const int g = c >> 5, w = (c & 31) * 2;                                          \
+                short4v lo = tr_read(as + r0 * (BM * 2) + ((g ^ swz_key<BM * 2>(r0)) << 6) + w); \
+                short4v hi = tr_read(as + r1 * (BM * 2) + ((g ^ swz_key<BM * 2>(r1)) << 6) + w); \
+                af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)); \
+            }                                                                                    \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                      \
+                const int c = wn * 64 + j * 32 + cofs;                                           \
+                const int g = c >> 5, w = (c & 31) * 2;                                          \
+                short4v lo = tr_read(bs + r0 * (BN * 2) + ((g ^ swz_key<BN * 2>(r0)) << 6) + w); \
+                short4v hi = tr_read(bs + r1 * (BN * 2) + ((g ^ swz_key<BN * 2>(r1)) << 6) + w); \
+                bf[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)); \
+            }                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                        \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                    \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0); \
+        }                                                                                        \
+    }
+
+    // tiles past the block's range load zeros (never consumed), so the loop carries no conditions
+    DPA_WG_LOAD(ar0, br0)
+    DPA_WG_LOAD(ar1, br1)
+    DPA_WG_LOAD(ar2, br2)
+    DPA_WG_STORE(0, ar0, br0)
     __syncthreads();
-    int cur = 0;
-    for (int st = 0; st < nsteps; ++st) {
-        if (st + 1 < nsteps) load_tile(st + 1);
-        const unsigned char* as = smem + cur * STAGE;
-        const unsigned char* bs = as + A_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[2], bf[2];
-            const int r0 = kk * 16 + kofs, r1 = r0 + 4;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int c = wm * 64 + i * 32 + cofs;  // element column in the dy tile
-                const int g = c >> 5, w = (c & 31) * 2;
-                short4v lo = tr_read(as + r0 * (BM * 2) + ((g ^ swz_key<BM * 2>(r0)) << 6) + w);
-                short4v hi = tr_read(as + r1 * (BM * 2) + ((g ^ swz_key<BM * 2>(r1)) << 6) + w);
-                af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int c = wn * 64 + j * 32 + cofs;
-                const int g = c >> 5, w = (c & 31) * 2;
-                short4v lo = tr_read(bs + r0 * (BN * 2) + ((g ^ swz_key<BN * 2>(r0)) << 6) + w);
-                short4v hi = tr_read(bs + r1 * (BN * 2) + ((g ^ swz_key<BN * 2>(r1)) << 6) + w);
-                bf[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        if (st + 1 < nsteps) store_tile(cur ^ 1);
+    int t = 0;
+    for (; t + 2 < nsteps; t += 3) {
+        DPA_WG_LOAD(ar0, br0)              // tile t + 3
+        __builtin_amdgcn_sched_barrier(0);
+        DPA_WG_COMPUTE(0)                  // tile t
+        DPA_WG_STORE(1, ar1, br1)          // tile t + 1
         __syncthreads();
-        cur ^= 1;
+        DPA_WG_LOAD(ar1, br1)              // tile t + 4
+        __builtin_amdgcn_sched_barrier(0);
+        DPA_WG_COMPUTE(1)
+        DPA_WG_STORE(2, ar2, br2)          // tile t + 2
+        __syncthreads();
+        DPA_WG_LOAD(ar2, br2)              // tile t + 5
+        __builtin_amdgcn_sched_barrier(0);
+        DPA_WG_COMPUTE(2)
+        DPA_WG_STORE(0, ar0, br0)          // tile t + 3
+        __syncthreads();
+    }
+    if (t < nsteps) {                      // one or two tiles left; buffer 0 holds tile t
+        DPA_WG_COMPUTE(0)
+        if (t + 1 < nsteps) {
+            DPA_WG_STORE(1, ar1, br1)
+            __syncthreads();
+            DPA_WG_COMPUTE(1)
+        }
     }
 
     // ---- accumulate into fp32 dw: each register = 2 rows x 32 contiguous columns ----
@@ -209,7 +268,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int tiles_
         }
 }
 
-template <int WM, int WN>
+#undef DPA_WG_LOAD
+#undef DPA_WG_STORE
+#undef DPA_WG_COMPUTE
+
+int wgrad_target_blocks() {
+    static int v = [] {
+        const char* e = getenv("DPA_WGRAD_BLOCKS");
+        return e ? atoi(e) : 512;
+    }();
+    return v;
+}
+
+template <int WM, int WN, bool LIN>
 void launch(const WgradArgs& a, hipStream_t st) {
     const long P = (long)a.N * a.Ho * a.Wo;
     const int Kg = a.R * a.S * a.C;
@@ -219,22 +290,23 @@ void launch(const WgradArgs& a, hipStream_t st) {
     const int steps = (int)((P + BKP - 1) / BKP);
     // ~2 workgroups per CU: every extra split adds a full fp32 copy of dw to the atomic traffic
     // (chip-wide float-atomic rate is ~1.3 TB/s), so do not over-split large filters.
-    int split = 512 / tiles;
+    int split = wgrad_target_blocks() / tiles;
     if (split < 1) split = 1;
     int max_split = steps / 8;
     if (max_split < 1) max_split = 1;
     if (split > max_split) split = max_split;
     const int sps = (steps + split - 1) / split;
     split = (steps + sps - 1) / sps;
-    dim3 grid(tiles, split), block(256);
-    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN>), grid, block, 0, st, a, tiles_n, P, Kg, sps);
+    dim3 grid(tiles * split), block(256);
+    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, LIN>), grid, block, 0, st, a, tiles_n, tiles, P, Kg, sps);
 }
 
 }  // namespace
 
 void conv_wgrad(const WgradArgs& a, hipStream_t st) {
-    if (a.K <= 64) launch<1, 4>(a, st);
-    else launch<2, 2>(a, st);
+    const bool lin = a.R == 1 && a.S == 1 && a.pad == 0 && a.stride == 1;
+    if (a.K <= 64) { if (lin) launch<1, 4, true>(a, st); else launch<1, 4, false>(a, st); }
+    else           { if (lin) launch<2, 2, true>(a, st); else launch<2, 2, false>(a, st); }
 }
 
 }  // namespace dpa
