@@ -76,7 +76,7 @@ std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::opti
 
 // dgrad: dy [N,Ho,Wo,K] bf16, wt [C,R,S,K] bf16 (filter with K and C swapped) -> dx [N,H,W,C]
 Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int64_t stride, int64_t pad,
-                  const c10::optional<Tensor>& addend) {
+                  const c10::optional<Tensor>& addend, const c10::optional<Tensor>& addend_mask) {
     CHECK_BF16(dy); CHECK_BF16(wt);
     TORCH_CHECK(dy.dim() == 4 && wt.dim() == 4, "conv_dgrad: 4-D tensors expected");
     const int64_t N = dy.size(0), Ho = dy.size(1), Wo = dy.size(2), K = dy.size(3);
@@ -94,6 +94,11 @@ Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int6
         CHECK_BF16((*addend));
         TORCH_CHECK(addend->numel() == N * H * W * C, "conv_dgrad: addend shape");
         a.addend = addend->data_ptr();
+        if (addend_mask.has_value() && addend_mask->defined()) {
+            TORCH_CHECK(addend_mask->scalar_type() == at::kByte && addend_mask->is_contiguous() && addend_mask->numel() * 8 == addend->numel(),
+                        "conv_dgrad: addend_mask must be uint8 with one bit per addend element");
+            a.addend_mask = addend_mask->data_ptr<uint8_t>();
+        }
     }
     a.N = N; a.H = Ho; a.W = Wo; a.C = K; a.K = C; a.R = R; a.S = S; a.Ho = H; a.Wo = W;
     a.stride = stride; a.pad = pad; a.mode = 1; a.act = 0;
@@ -179,7 +184,9 @@ std::vector<Tensor> bn_finalize(const Tensor& stats_in, int64_t P, const Tensor&
     return {out[0], out[1], out[2], out[3]};
 }
 
-Tensor bn_apply(const Tensor& x, const c10::optional<Tensor>& residual, const Tensor& scale, const Tensor& shift, bool relu) {
+// returns (y, mask): mask is the uint8 bit mask (y > 0) when relu && want_mask, else undefined
+std::vector<Tensor> bn_apply(const Tensor& x, const c10::optional<Tensor>& residual, const Tensor& scale, const Tensor& shift,
+                             bool relu, bool want_mask) {
     CHECK_BF16(x); CHECK_F32(scale); CHECK_F32(shift);
     const int64_t C = x.size(-1), P = x.numel() / C;
     TORCH_CHECK(C % 8 == 0 && scale.numel() == C && shift.numel() == C, "bn_apply: bad channel count");
@@ -191,18 +198,28 @@ Tensor bn_apply(const Tensor& x, const c10::optional<Tensor>& residual, const Te
     }
     Guard g(x);
     Tensor y = torch::empty_like(x);
-    dpa::bn_apply(x.data_ptr(), res, y.data_ptr(), scale.data_ptr<float>(), shift.data_ptr<float>(), P, C, relu, cur_stream());
-    return y;
+    Tensor mask;
+    if (relu && want_mask) mask = torch::empty({x.numel() / 8}, x.options().dtype(at::kByte));
+    dpa::bn_apply(x.data_ptr(), res, y.data_ptr(), scale.data_ptr<float>(), shift.data_ptr<float>(),
+                  mask.defined() ? mask.data_ptr<uint8_t>() : nullptr, P, C, relu, cur_stream());
+    return {y, mask};
 }
 
-// returns (dx, dres or undefined, dgamma, dbeta)
-std::vector<Tensor> bn_backward(const Tensor& dy, const Tensor& y, const Tensor& x, const Tensor& gamma, const Tensor& mean,
-                                const Tensor& invstd, bool relu, bool want_dres, const c10::optional<Tensor>& dgamma_acc,
+// returns (dx, dgamma, dbeta).  relu: `mask` is the bit mask written by bn_apply (the gradient
+// of a residual branch is dy under the same mask: relu_mask_mul, or the dgrad addend_mask).
+std::vector<Tensor> bn_backward(const Tensor& dy, const c10::optional<Tensor>& mask, const Tensor& x, const Tensor& gamma,
+                                const Tensor& mean, const Tensor& invstd, bool relu, const c10::optional<Tensor>& dgamma_acc,
                                 const c10::optional<Tensor>& dbeta_acc, const c10::optional<Tensor>& stats_buf) {
-    CHECK_BF16(dy); CHECK_BF16(y); CHECK_BF16(x); CHECK_F32(gamma); CHECK_F32(mean); CHECK_F32(invstd);
+    CHECK_BF16(dy); CHECK_BF16(x); CHECK_F32(gamma); CHECK_F32(mean); CHECK_F32(invstd);
     const int64_t C = x.size(-1), P = x.numel() / C;
-    TORCH_CHECK(dy.numel() == x.numel() && y.numel() == x.numel(), "bn_backward: shape mismatch");
+    TORCH_CHECK(dy.numel() == x.numel(), "bn_backward: shape mismatch");
     TORCH_CHECK(C % 8 == 0 && C <= 2048 && gamma.numel() == C && mean.numel() == C && invstd.numel() == C, "bn_backward: channels");
+    const uint8_t* mk = nullptr;
+    if (relu) {
+        TORCH_CHECK(mask.has_value() && mask->defined() && mask->scalar_type() == at::kByte && mask->is_contiguous() &&
+                    mask->numel() * 8 == x.numel(), "bn_backward: relu needs the uint8 bit mask from bn_apply");
+        mk = mask->data_ptr<uint8_t>();
+    }
     Guard g(x);
     auto fopt = x.options().dtype(at::kFloat);
     int rows; int replicas = 0; int reset = 0;
@@ -216,7 +233,7 @@ std::vector<Tensor> bn_backward(const Tensor& dy, const Tensor& y, const Tensor&
         rows = dpa::bn_stats_rows(P);
         stats = torch::empty({rows, 2, C}, fopt);
     }
-    dpa::bn_bwd_stats(dy.data_ptr(), y.data_ptr(), x.data_ptr(), mean.data_ptr<float>(), invstd.data_ptr<float>(),
+    dpa::bn_bwd_stats(dy.data_ptr(), mk, x.data_ptr(), mean.data_ptr<float>(), invstd.data_ptr<float>(),
                       stats.data_ptr<float>(), P, C, relu, replicas, cur_stream());
     if (replicas == 0 && rows > 256) {
         const int chunk = 64;
@@ -235,11 +252,17 @@ std::vector<Tensor> bn_backward(const Tensor& dy, const Tensor& y, const Tensor&
     dpa::bn_bwd_finalize(stats.data_ptr<float>(), rows, P, C, gamma.data_ptr<float>(), mean.data_ptr<float>(),
                          invstd.data_ptr<float>(), dg, db, accumulate, o + 2 * C, o + 3 * C, o + 4 * C, reset, cur_stream());
     Tensor dx = torch::empty_like(x);
-    Tensor dres;
-    if (want_dres) dres = torch::empty_like(x);
-    dpa::bn_bwd_apply(dy.data_ptr(), y.data_ptr(), x.data_ptr(), o + 2 * C, o + 3 * C, o + 4 * C, dx.data_ptr(),
-                      want_dres ? dres.data_ptr() : nullptr, P, C, relu, cur_stream());
-    return {dx, dres, co[0], co[1]};
+    dpa::bn_bwd_apply(dy.data_ptr(), mk, x.data_ptr(), o + 2 * C, o + 3 * C, o + 4 * C, dx.data_ptr(), P, C, relu, cur_stream());
+    return {dx, co[0], co[1]};
+}
+
+Tensor relu_mask_mul(const Tensor& dy, const Tensor& mask) {
+    CHECK_BF16(dy);
+    TORCH_CHECK(mask.scalar_type() == at::kByte && mask.is_contiguous() && mask.numel() * 8 == dy.numel(), "relu_mask_mul: mask size");
+    Guard g(dy);
+    Tensor out = torch::empty_like(dy);
+    dpa::relu_mask_mul(dy.data_ptr(), mask.data_ptr<uint8_t>(), out.data_ptr(), dy.numel(), cur_stream());
+    return out;
 }
 
 // ---------------------------------------------------------------- pooling / layout / elementwise
@@ -515,6 +538,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("bn_stats", &bn_stats);
     m.def("bn_finalize", &bn_finalize);
     m.def("bn_apply", &bn_apply);
+    m.def("relu_mask_mul", &relu_mask_mul);
     m.def("bn_backward", &bn_backward);
     m.def("maxpool_fwd", &maxpool_fwd);
     m.def("maxpool_bwd", &maxpool_bwd);

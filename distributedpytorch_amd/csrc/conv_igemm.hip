@@ -291,6 +291,11 @@ __global__ __launch_bounds__(256, (WP == 4 && !ONE) ? 2 : 3) void conv_igemm_ker
                 const uint4 ad = *(const uint4*)(addg + orow_g * a.K + co);
                 float f[8], g[8];
                 unpack8(v, f); unpack8(ad, g);
+                if (a.addend_mask != nullptr) {
+                    const unsigned mk = a.addend_mask[(orow_g * a.K + co) >> 3];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] = ((mk >> j) & 1u) ? g[j] : 0.f;
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] += g[j];
                 v = pack8(f);

@@ -23,6 +23,8 @@ struct ConvArgs {
                         // (pixel tile mod stats_rows); must be zero before the launch; or nullptr
     int stats_rows;
     const void* addend; // bf16 [N, Ho, Wo, K] added to the output (residual-gradient fusion), or nullptr
+    const unsigned char* addend_mask;  // optional bit mask (1 bit per addend element, 8 per byte): masked-out
+                                       // elements of addend count as 0 (ReLU gradient of the residual join)
     int N, H, W, C, K, R, S, Ho, Wo;
     int stride, pad;
     int mode;           // 0 fprop, 1 dgrad
@@ -58,19 +60,22 @@ void bn_finalize(float* stats, int rows, long P, int C, const float* gamma, cons
                  float* running_mean, float* running_var, float momentum, float eps,
                  float* mean, float* invstd, float* scale, float* shift, int reset_stats, hipStream_t st);
 // y = act(x*scale[c] + shift[c] (+ residual))
+// relu: optionally also emits the bit mask (y > 0), one byte per 8 elements, that the backward kernels read
 void bn_apply(const void* x, const void* residual, void* y, const float* scale, const float* shift,
-              long P, int C, int relu, hipStream_t st);
-// backward pass 1: g = dy * (relu ? y>0 : 1); partial sums of g and g*xhat per block of rows
+              unsigned char* mask, long P, int C, int relu, hipStream_t st);
+// backward pass 1: g = dy * (relu ? mask : 1); partial sums of g and g*xhat per block of rows
 // (replicas > 0: added with atomics into a zeroed [replicas][2][C] buffer instead)
-void bn_bwd_stats(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+void bn_bwd_stats(const void* dy, const unsigned char* mask, const void* x, const float* mean, const float* invstd,
                   float* stats, long P, int C, int relu, int replicas, hipStream_t st);
 // reduce partials -> dgamma, dbeta (accumulate=0: overwrite) and coefficients A,B,C0 with dx = A*g + B*x + C0
 void bn_bwd_finalize(float* stats, int rows, long P, int C, const float* gamma, const float* mean,
                      const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coefA, float* coefB,
                      float* coefC, int reset_stats, hipStream_t st);
-// backward pass 2: dx = A*g + B*x + C0 ; optionally dres = g
-void bn_bwd_apply(const void* dy, const void* y, const void* x, const float* coefA, const float* coefB,
-                  const float* coefC, void* dx, void* dres, long P, int C, int relu, hipStream_t st);
+// backward pass 2: dx = A*g + B*x + C0
+void bn_bwd_apply(const void* dy, const unsigned char* mask, const void* x, const float* coefA, const float* coefB,
+                  const float* coefC, void* dx, long P, int C, int relu, hipStream_t st);
+// out = dy where the mask bit is set, else 0 (n % 8 == 0)
+void relu_mask_mul(const void* dy, const unsigned char* mask, void* out, long n, hipStream_t st);
 
 // ---------------------------------------------------------------- pooling / layout
 void maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int Ho, int Wo, hipStream_t st);

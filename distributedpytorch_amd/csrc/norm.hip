@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(float* __restrict__ st
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ res,
                                                        unsigned short* __restrict__ y, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, long nchunks, int cpr) {
+                                                       const float* __restrict__ shift, unsigned char* __restrict__ mask,
+                                                       long nchunks, int cpr) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long)gridDim.x * 256) {
         const int ch = (int)(i % cpr);
         uint4 v = *(const uint4*)(x + i * 8);
@@ -123,11 +124,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
             f[j] = t;
         }
         *(uint4*)(y + i * 8) = pack8(f);
+        if (RELU && mask != nullptr) {      // one bit per element: the backward pass reads 1/16 of the bytes of y
+            unsigned m = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m |= (f[j] > 0.f ? 1u : 0u) << j;
+            mask[i] = (unsigned char)m;
+        }
     }
 }
 
 template <bool RELU>
-__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ y,
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const unsigned short* __restrict__ dy, const unsigned char* __restrict__ mask,
                                                            const unsigned short* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, float* __restrict__ stats,
                                                            long P, int C, int rpb, int replicas) {
@@ -136,10 +143,9 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const unsigned short*
         uint4 xv = *(const uint4*)(x + r * C + ch * 8);
         float g[8], xf[8]; unpack8(dv, g); unpack8(xv, xf);
         if (RELU) {
-            uint4 yv = *(const uint4*)(y + r * C + ch * 8);
-            float yf[8]; unpack8(yv, yf);
+            const unsigned m = mask[(r * C) / 8 + ch];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] = yf[j] > 0.f ? g[j] : 0.f;
+            for (int j = 0; j < 8; ++j) g[j] = ((m >> j) & 1u) ? g[j] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -180,28 +186,40 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
     }
 }
 
-template <bool RELU, bool RES>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ y,
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* __restrict__ dy, const unsigned char* __restrict__ mask,
                                                            const unsigned short* __restrict__ x, const float* __restrict__ cA,
                                                            const float* __restrict__ cB, const float* __restrict__ cC,
-                                                           unsigned short* __restrict__ dx, unsigned short* __restrict__ dres,
-                                                           long nchunks, int cpr) {
+                                                           unsigned short* __restrict__ dx, long nchunks, int cpr) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long)gridDim.x * 256) {
         const int ch = (int)(i % cpr);
         float g[8], xf[8];
         { uint4 v = *(const uint4*)(dy + i * 8); unpack8(v, g); }
         { uint4 v = *(const uint4*)(x + i * 8); unpack8(v, xf); }
         if (RELU) {
-            uint4 yv = *(const uint4*)(y + i * 8);
-            float yf[8]; unpack8(yv, yf);
+            const unsigned m = mask[i];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] = yf[j] > 0.f ? g[j] : 0.f;
+            for (int j = 0; j < 8; ++j) g[j] = ((m >> j) & 1u) ? g[j] : 0.f;
         }
-        if (RES) *(uint4*)(dres + i * 8) = pack8(g);
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = cA[ch * 8 + j] * g[j] + cB[ch * 8 + j] * xf[j] + cC[ch * 8 + j];
         *(uint4*)(dx + i * 8) = pack8(o);
+    }
+}
+
+// dy * relu-mask (the gradient that flows into a residual branch), for the op-by-op autograd path
+__global__ __launch_bounds__(256) void relu_mask_mul_kernel(const unsigned short* __restrict__ dy, const unsigned char* __restrict__ mask,
+                                                            unsigned short* __restrict__ out, long nchunks) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long)gridDim.x * 256) {
+        u32x4 v = *(const u32x4*)(dy + i * 8);
+        const unsigned m = mask[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned keep = (((m >> (2 * j)) & 1u) ? 0x0000ffffu : 0u) | (((m >> (2 * j + 1)) & 1u) ? 0xffff0000u : 0u);
+            v[j] &= keep;
+        }
+        *(u32x4*)(out + i * 8) = v;
     }
 }
 
@@ -245,26 +263,26 @@ void bn_finalize(float* stats, int rows, long P, int C, const float* gamma, cons
 }
 
 void bn_apply(const void* x, const void* residual, void* y, const float* scale, const float* shift,
-              long P, int C, int relu, hipStream_t st) {
+              unsigned char* mask, long P, int C, int relu, hipStream_t st) {
     const long nchunks = P * C / 8;
     const int cpr = C / 8;
     dim3 g(stream_grid(nchunks)), b(256);
     auto X = (const unsigned short*)x; auto R = (const unsigned short*)residual; auto Y = (unsigned short*)y;
     if (relu) {
-        if (R) hipLaunchKernelGGL((bn_apply_kernel<true, true>), g, b, 0, st, X, R, Y, scale, shift, nchunks, cpr);
-        else   hipLaunchKernelGGL((bn_apply_kernel<true, false>), g, b, 0, st, X, R, Y, scale, shift, nchunks, cpr);
+        if (R) hipLaunchKernelGGL((bn_apply_kernel<true, true>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr);
+        else   hipLaunchKernelGGL((bn_apply_kernel<true, false>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr);
     } else {
-        if (R) hipLaunchKernelGGL((bn_apply_kernel<false, true>), g, b, 0, st, X, R, Y, scale, shift, nchunks, cpr);
-        else   hipLaunchKernelGGL((bn_apply_kernel<false, false>), g, b, 0, st, X, R, Y, scale, shift, nchunks, cpr);
+        if (R) hipLaunchKernelGGL((bn_apply_kernel<false, true>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr);
+        else   hipLaunchKernelGGL((bn_apply_kernel<false, false>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr);
     }
 }
 
-void bn_bwd_stats(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+void bn_bwd_stats(const void* dy, const unsigned char* mask, const void* x, const float* mean, const float* invstd,
                   float* stats, long P, int C, int relu, int replicas, hipStream_t st) {
     dim3 g(bn_stats_rows(P)), b(256);
-    if (relu) hipLaunchKernelGGL((bn_bwd_stats_kernel<true>), g, b, 0, st, (const unsigned short*)dy, (const unsigned short*)y,
+    if (relu) hipLaunchKernelGGL((bn_bwd_stats_kernel<true>), g, b, 0, st, (const unsigned short*)dy, mask,
                                  (const unsigned short*)x, mean, invstd, stats, P, C, rows_per_block(P), replicas);
-    else      hipLaunchKernelGGL((bn_bwd_stats_kernel<false>), g, b, 0, st, (const unsigned short*)dy, (const unsigned short*)y,
+    else      hipLaunchKernelGGL((bn_bwd_stats_kernel<false>), g, b, 0, st, (const unsigned short*)dy, mask,
                                  (const unsigned short*)x, mean, invstd, stats, P, C, rows_per_block(P), replicas);
 }
 
@@ -275,20 +293,21 @@ void bn_bwd_finalize(float* stats, int rows, long P, int C, const float* gamma, 
                        dgamma, dbeta, accumulate, coefA, coefB, coefC, reset_stats);
 }
 
-void bn_bwd_apply(const void* dy, const void* y, const void* x, const float* coefA, const float* coefB,
-                  const float* coefC, void* dx, void* dres, long P, int C, int relu, hipStream_t st) {
+void bn_bwd_apply(const void* dy, const unsigned char* mask, const void* x, const float* coefA, const float* coefB,
+                  const float* coefC, void* dx, long P, int C, int relu, hipStream_t st) {
     const long nchunks = P * C / 8;
     const int cpr = C / 8;
     dim3 g(stream_grid(nchunks)), b(256);
-    auto DY = (const unsigned short*)dy; auto Y = (const unsigned short*)y; auto X = (const unsigned short*)x;
-    auto DX = (unsigned short*)dx; auto DR = (unsigned short*)dres;
-    if (relu) {
-        if (DR) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), g, b, 0, st, DY, Y, X, coefA, coefB, coefC, DX, DR, nchunks, cpr);
-        else    hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), g, b, 0, st, DY, Y, X, coefA, coefB, coefC, DX, DR, nchunks, cpr);
-    } else {
-        if (DR) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), g, b, 0, st, DY, Y, X, coefA, coefB, coefC, DX, DR, nchunks, cpr);
-        else    hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), g, b, 0, st, DY, Y, X, coefA, coefB, coefC, DX, DR, nchunks, cpr);
-    }
+    auto DY = (const unsigned short*)dy; auto X = (const unsigned short*)x;
+    auto DX = (unsigned short*)dx;
+    if (relu) hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr);
+    else      hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr);
+}
+
+void relu_mask_mul(const void* dy, const unsigned char* mask, void* out, long n, hipStream_t st) {
+    const long nchunks = n / 8;
+    hipLaunchKernelGGL(relu_mask_mul_kernel, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const unsigned short*)dy, mask,
+                       (unsigned short*)out, nchunks);
 }
 
 }  // namespace dpa

@@ -29,21 +29,20 @@ def _conv_bn_fwd(C, conv, bn, x, relu, residual=None):
     P = y.numel() // y.shape[-1]
     mean, invstd, scale, shift = C.bn_finalize(stats, P, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                                bn.running_var, bn.momentum, bn.eps, True)
-    a = C.bn_apply(y, residual, scale, shift, relu)
-    return y, a, mean, invstd
+    a, mask = C.bn_apply(y, residual, scale, shift, relu, relu)
+    return y, a, mean, invstd, mask
 
 
-def _bn_bwd(C, bn, dy, y_act, x_raw, mean, invstd, relu, want_res, grads, slot):
+def _bn_bwd(C, bn, dy, mask, x_raw, mean, invstd, relu, grads, slot):
     tg, tb = _sink.target(bn.weight), _sink.target(bn.bias)
     if tg is not None and tb is not None:
-        dx, dres, _, _ = C.bn_backward(dy, y_act, x_raw, bn.weight.detach(), mean, invstd, relu, want_res, tg, tb,
-                                       bn.stats_buffer_bwd(dy.device))
+        dx, _, _ = C.bn_backward(dy, mask, x_raw, bn.weight.detach(), mean, invstd, relu, tg, tb, bn.stats_buffer_bwd(dy.device))
         _sink.ready(bn.weight); _sink.ready(bn.bias)
     else:
-        dx, dres, dg, db = C.bn_backward(dy, y_act, x_raw, bn.weight.detach(), mean, invstd, relu, want_res, None, None,
-                                         bn.stats_buffer_bwd(dy.device))
+        dx, dg, db = C.bn_backward(dy, mask, x_raw, bn.weight.detach(), mean, invstd, relu, None, None,
+                                   bn.stats_buffer_bwd(dy.device))
         grads[slot], grads[slot + 1] = dg, db
-    return dx, dres
+    return dx
 
 
 def _wgrad(C, conv, x, dy, grads, slot):
@@ -63,14 +62,15 @@ class _BottleneckFn(torch.autograd.Function):
         C = _ext.load()
         ds = blk.downsample is not None
         if ds:
-            cd, idn, md, isd = _conv_bn_fwd(C, blk.downsample[0], blk.downsample[1], x, False)
+            cd, idn, md, isd, _ = _conv_bn_fwd(C, blk.downsample[0], blk.downsample[1], x, False)
         else:
             cd = md = isd = None
             idn = x
-        c1, a1, m1, i1 = _conv_bn_fwd(C, blk.conv1, blk.bn1, x, True)
-        c2, a2, m2, i2 = _conv_bn_fwd(C, blk.conv2, blk.bn2, a1, True)
-        c3, out, m3, i3 = _conv_bn_fwd(C, blk.conv3, blk.bn3, a2, True, idn)
-        saved = [x, c1, a1, m1, i1, c2, a2, m2, i2, c3, out, m3, i3]
+        c1, a1, m1, i1, k1 = _conv_bn_fwd(C, blk.conv1, blk.bn1, x, True)
+        c2, a2, m2, i2, k2 = _conv_bn_fwd(C, blk.conv2, blk.bn2, a1, True)
+        c3, out, m3, i3, k3 = _conv_bn_fwd(C, blk.conv3, blk.bn3, a2, True, idn)
+        # the ReLU masks travel as 1 bit per element: the backward pass never re-reads an activation for its sign
+        saved = [x, c1, a1, m1, i1, k1, c2, a2, m2, i2, k2, c3, m3, i3, k3]
         if ds:
             saved += [cd, md, isd]
         ctx.save_for_backward(*saved)
@@ -83,33 +83,34 @@ class _BottleneckFn(torch.autograd.Function):
         blk = ctx.blk
         ds = blk.downsample is not None
         sv = ctx.saved_tensors
-        x, c1, a1, m1, i1, c2, a2, m2, i2, c3, out, m3, i3 = sv[:13]
+        x, c1, a1, m1, i1, k1, c2, a2, m2, i2, k2, c3, m3, i3, k3 = sv[:15]
         dout = dout.contiguous()
         n_params = 12 if ds else 9
         grads = [None] * n_params          # order: conv1.w bn1.w bn1.b conv2.w bn2.w bn2.b conv3.w bn3.w bn3.b [ds.w dsbn.w dsbn.b]
-        # bn3 (+ residual join, ReLU mask from the block output): d(conv3 out) and the residual-branch gradient
-        d3, dres = _bn_bwd(C, blk.bn3, dout, out, c3, m3, i3, True, True, grads, 7)
+        # bn3 behind the residual join: the masked dout is both bn3's incoming gradient and the gradient of the
+        # shortcut branch; it is never materialised (consumers apply the bit mask k3 themselves)
+        d3 = _bn_bwd(C, blk.bn3, dout, k3, c3, m3, i3, True, grads, 7)
         _wgrad(C, blk.conv3, a2, d3, grads, 6)
-        da2 = C.conv_dgrad(d3, C.transpose_filter(blk.conv3.weight_lp), a2.shape[1], a2.shape[2], 1, 0, None)
-        d2, _ = _bn_bwd(C, blk.bn2, da2, a2, c2, m2, i2, True, False, grads, 4)
+        da2 = C.conv_dgrad(d3, C.transpose_filter(blk.conv3.weight_lp), a2.shape[1], a2.shape[2], 1, 0, None, None)
+        d2 = _bn_bwd(C, blk.bn2, da2, k2, c2, m2, i2, True, grads, 4)
         _wgrad(C, blk.conv2, a1, d2, grads, 3)
         da1 = C.conv_dgrad(d2, C.transpose_filter(blk.conv2.weight_lp), a1.shape[1], a1.shape[2],
-                           blk.conv2.stride, blk.conv2.padding, None)
-        d1, _ = _bn_bwd(C, blk.bn1, da1, a1, c1, m1, i1, True, False, grads, 1)
+                           blk.conv2.stride, blk.conv2.padding, None, None)
+        d1 = _bn_bwd(C, blk.bn1, da1, k1, c1, m1, i1, True, grads, 1)
         _wgrad(C, blk.conv1, x, d1, grads, 0)
         dx = None
         need_dx = ctx.needs_input_grad[0]
         if ds:
-            cd, md, isd = sv[13:16]
+            cd, md, isd = sv[15:18]
             dconv = blk.downsample[0]
-            dd, _ = _bn_bwd(C, blk.downsample[1], dres, cd, cd, md, isd, False, False, grads, 10)
+            dd = _bn_bwd(C, blk.downsample[1], dout, k3, cd, md, isd, True, grads, 10)   # "relu" = the join's mask
             _wgrad(C, dconv, x, dd, grads, 9)
             if need_dx:
-                dxd = C.conv_dgrad(dd, C.transpose_filter(dconv.weight_lp), x.shape[1], x.shape[2], dconv.stride, 0, None)
-                dx = C.conv_dgrad(d1, C.transpose_filter(blk.conv1.weight_lp), x.shape[1], x.shape[2], 1, 0, dxd)
+                dxd = C.conv_dgrad(dd, C.transpose_filter(dconv.weight_lp), x.shape[1], x.shape[2], dconv.stride, 0, None, None)
+                dx = C.conv_dgrad(d1, C.transpose_filter(blk.conv1.weight_lp), x.shape[1], x.shape[2], 1, 0, dxd, None)
         elif need_dx:
-            # identity shortcut: the residual gradient is added in the dgrad epilogue
-            dx = C.conv_dgrad(d1, C.transpose_filter(blk.conv1.weight_lp), x.shape[1], x.shape[2], 1, 0, dres)
+            # identity shortcut: the masked residual gradient is added in the dgrad epilogue
+            dx = C.conv_dgrad(d1, C.transpose_filter(blk.conv1.weight_lp), x.shape[1], x.shape[2], 1, 0, dout, k3)
         return (dx, None, *grads)
 
 

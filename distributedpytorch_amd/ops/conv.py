@@ -54,7 +54,7 @@ class _ConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = C.conv_dgrad(dy, C.transpose_filter(w), x.shape[1], x.shape[2], stride, pad, None)
+            dx = C.conv_dgrad(dy, C.transpose_filter(w), x.shape[1], x.shape[2], stride, pad, None, None)
         weight = ctx.weight
         if weight.requires_grad:
             tgt = _sink.target(weight)

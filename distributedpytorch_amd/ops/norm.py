@@ -37,8 +37,11 @@ class _BNTrainFn(torch.autograd.Function):
             reset_stats = False
         mean, invstd, scale, shift = C.bn_finalize(stats, P, gamma.detach(), beta.detach(), running_mean, running_var,
                                                    momentum, eps, reset_stats)
-        y = C.bn_apply(x, residual, scale, shift, relu)
-        ctx.save_for_backward(x, y if relu else x, mean, invstd)
+        y, mask = C.bn_apply(x, residual, scale, shift, relu, relu)   # relu: 1 bit / element for the backward pass
+        if relu:
+            ctx.save_for_backward(x, mean, invstd, mask)
+        else:
+            ctx.save_for_backward(x, mean, invstd)
         ctx.gamma, ctx.beta = gamma, beta
         ctx.relu, ctx.has_res = relu, residual is not None
         return y
@@ -46,19 +49,25 @@ class _BNTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         C = _ext.load()
-        x, y, mean, invstd = ctx.saved_tensors
+        if ctx.relu:
+            x, mean, invstd, mask = ctx.saved_tensors
+        else:
+            (x, mean, invstd), mask = ctx.saved_tensors, None
         dy = dy.contiguous()
         want_res = ctx.has_res and ctx.needs_input_grad[6]
         tg, tb = _sink.target(ctx.gamma), _sink.target(ctx.beta)
         if tg is not None and tb is not None:       # finalize kernel adds straight into the flat gradient buffer
-            dx, dres, _, _ = C.bn_backward(dy, y, x, ctx.gamma.detach(), mean, invstd, ctx.relu, want_res, tg, tb, None)
+            dx, _, _ = C.bn_backward(dy, mask, x, ctx.gamma.detach(), mean, invstd, ctx.relu, tg, tb, None)
             _sink.ready(ctx.gamma); _sink.ready(ctx.beta)
             dg = db = None
         else:
-            dx, dres, dgamma, dbeta = C.bn_backward(dy, y, x, ctx.gamma.detach(), mean, invstd, ctx.relu, want_res, None, None, None)
+            dx, dgamma, dbeta = C.bn_backward(dy, mask, x, ctx.gamma.detach(), mean, invstd, ctx.relu, None, None, None)
             dg = dgamma if ctx.gamma.requires_grad else None
             db = dbeta if ctx.beta.requires_grad else None
-        return dx, None, dg, db, None, None, (dres if want_res else None), None, None, None, None
+        dres = None
+        if want_res:                                # gradient of the residual branch: dy under the ReLU mask
+            dres = C.relu_mask_mul(dy, mask) if ctx.relu else dy
+        return dx, None, dg, db, None, None, dres, None, None, None, None
 
 
 def batch_norm_nhwc(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
@@ -75,7 +84,7 @@ def batch_norm_nhwc(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
         # inference: fold running stats into scale/shift (cold path), apply with the same streaming kernel
         scale = (gamma.detach() * torch.rsqrt(running_var + eps)).float().contiguous()
         shift = (beta.detach() - running_mean * scale).float().contiguous()
-        return C.bn_apply(x, residual, scale, shift, relu)
+        return C.bn_apply(x, residual, scale, shift, relu, False)[0]
     xc = x.permute(0, 3, 1, 2) if x.dim() == 4 else x
     y = F.batch_norm(xc.float(), running_mean, running_var, gamma, beta, training, momentum, eps).to(x.dtype)
     if x.dim() == 4:

@@ -78,7 +78,7 @@ def main():
         flops = 2.0 * N * Ho * Ho * K * R * R * Cin
         byts = 2.0 * (x.numel() + dy.numel() + w.numel())
         tf = timeit(lambda: C.conv_fprop(x, w, None, s, p, 0, True, sbuf), a.iters)
-        td = timeit(lambda: C.conv_dgrad(dy, wt, H, H, s, p, None), a.iters) if name != "stem7x7" else 0.0
+        td = timeit(lambda: C.conv_dgrad(dy, wt, H, H, s, p, None, None), a.iters) if name != "stem7x7" else 0.0
         tw = timeit(lambda: C.conv_wgrad(x, dy, dw, s, p), a.iters)
         rows.append(dict(name=name, count=cnt, fprop_us=tf, dgrad_us=td, wgrad_us=tw, gflop=flops / 1e9))
         tot["fprop"] += tf * cnt; tot["dgrad"] += td * cnt; tot["wgrad"] += tw * cnt

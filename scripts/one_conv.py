@@ -26,7 +26,7 @@ for _ in range(iters):
     if what == "fprop":
         C.conv_fprop(x, w, None, s, p, 0, True, sbuf)
     elif what == "dgrad":
-        C.conv_dgrad(dy, wt, H, H, s, p, None)
+        C.conv_dgrad(dy, wt, H, H, s, p, None, None)
     else:
         C.conv_wgrad(x, dy, dw, s, p)
 torch.cuda.synchronize()

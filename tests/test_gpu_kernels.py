@@ -97,15 +97,22 @@ def test_conv_dgrad(case):
     w = _rand_bf16(K, R, R, C, scale=1.0 / math.sqrt(R * R * K), seed=6)
     wt = _C().transpose_filter(w)
     assert torch.equal(wt, w.permute(3, 1, 2, 0).contiguous())
-    dx = _C().conv_dgrad(dy, wt, H, W, s, p, None)
+    dx = _C().conv_dgrad(dy, wt, H, W, s, p, None, None)
     xr = torch.zeros(N, C, H, W, requires_grad=True)
     yr = F.conv2d(xr, w.float().cpu().permute(0, 3, 1, 2), stride=s, padding=p)
     yr.backward(dy.float().cpu().permute(0, 3, 1, 2))
     _close(dx, xr.grad.permute(0, 2, 3, 1), 1e-2, 2e-2, "dgrad")
     # fused residual-gradient add in the epilogue
     add = _rand_bf16(N, H, W, C, seed=55)
-    dx2 = _C().conv_dgrad(dy, wt, H, W, s, p, add)
+    dx2 = _C().conv_dgrad(dy, wt, H, W, s, p, add, None)
     _close(dx2, xr.grad.permute(0, 2, 3, 1) + add.float().cpu(), 1e-2, 3e-2, "dgrad+addend")
+    # ... under a ReLU bit mask (1 bit per element, 8 per byte, LSB = lowest channel)
+    bits = torch.rand(N, H, W, C, generator=torch.Generator().manual_seed(56)) > 0.5
+    packed = (bits.view(-1, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(1).to(torch.uint8).to(DEV)
+    dx3 = _C().conv_dgrad(dy, wt, H, W, s, p, add, packed)
+    _close(dx3, xr.grad.permute(0, 2, 3, 1) + add.float().cpu() * bits, 1e-2, 3e-2, "dgrad+masked addend")
+    mm = _C().relu_mask_mul(add, packed)
+    assert torch.equal(mm.float().cpu(), add.float().cpu() * bits)
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
