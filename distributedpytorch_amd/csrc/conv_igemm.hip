@@ -36,6 +36,8 @@ namespace {
 constexpr int BK = 32;          // K step (bf16 elements)
 constexpr int CHUNKS = BK / 8;  // 16-byte chunks per tile row
 
+typedef __attribute__((address_space(3))) short4v* lds_s4_ptr;
+
 __device__ __forceinline__ int swz4(int row) {  // conflict-free chunk swizzle for 64-byte rows
     return (0x78 >> (2 * ((row >> 2) & 3))) & 3;  // {0,2,3,1}[(row>>2)&3]
 }
@@ -105,19 +107,24 @@ __global__ __launch_bounds__(256, (WP == 4 && !ONE) ? 2 : 3) void conv_igemm_ker
     const int PHW = PH * PW;
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
-        long m = m0 + lrow + i * 64;
+        const long m = m0 + lrow + i * 64;
         const bool rv = m < M;
-        long mm = rv ? m : 0;
-        int n = (int)(mm / PHW);
-        int rem = (int)(mm - (long)n * PHW);
-        int ho = rem / PW, wo = rem - ho * PW;
+        if (ONE && a.stride == 1) {              // GEMM row m is input pixel m: no index arithmetic at all
+            hi0[i] = 0; wi0[i] = 0;
+            xb[i] = rv ? (unsigned)m * (unsigned)a.C * 2u : xbytes;
+            continue;
+        }
+        const unsigned mm = rv ? (unsigned)m : 0u;      // M < 2^31 (host check): 32-bit divisions
+        const unsigned n = mm / (unsigned)PHW;
+        const unsigned rem = mm - n * (unsigned)PHW;
+        const int ho = (int)(rem / (unsigned)PW), wo = (int)(rem - (rem / (unsigned)PW) * (unsigned)PW);
         if (MODE == 0)      { hi0[i] = ho * a.stride - a.pad; wi0[i] = wo * a.stride - a.pad; }
         else if (MODE == 1) { hi0[i] = ho + a.pad;            wi0[i] = wo + a.pad; }
         else                { hi0[i] = (ho * a.stride + ph0 + a.pad - r0) / a.stride;   // exact division
                               wi0[i] = (wo * a.stride + pw0 + a.pad - s0) / a.stride; }
-        if (ONE) xb[i] = rv ? (unsigned)((n * a.H + hi0[i]) * a.W + wi0[i]) * (unsigned)a.C * 2u : xbytes;
+        if (ONE) xb[i] = rv ? (unsigned)(((int)n * a.H + hi0[i]) * a.W + wi0[i]) * (unsigned)a.C * 2u : xbytes;
         else {
-            xb[i] = (unsigned)(n * a.H * a.W);   // pixel index of the image origin
+            xb[i] = n * (unsigned)(a.H * a.W);   // pixel index of the image origin
             if (!rv) hi0[i] = -(1 << 24);        // never inside the image: the row gathers zeros
         }
     }
@@ -222,48 +229,83 @@ __global__ __launch_bounds__(256, (WP == 4 && !ONE) ? 2 : 3) void conv_igemm_ker
     // ---- epilogue: bias/activation, stage the bf16 tile in LDS ----
     unsigned short* cs = (unsigned short*)smem;
     const int q4 = (lane >> 4) * 4;
+    if (a.bias == nullptr && a.act == 0) {          // every BatchNorm-ed conv and every dgrad: pack and go
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int col = wc * 64 + i * 16 + q4;  // channel inside the block tile (4 consecutive)
-        float b[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias != nullptr) {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) b[r] = a.bias[min(c0 + col + r, a.K - 1)];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int pix = wp * 64 + j * 16 + frow;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t = acc[i][j][r] + b[r];
-                if (a.act == 1) t = fmaxf(t, 0.f);
-                else if (a.act == 2) t = gelu_tanh(t);
-                v[r] = t;
+            for (int j = 0; j < 4; ++j) {
+                uint2 pk;
+                pk.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+                pk.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+                *(uint2*)(cs + (wp * 64 + j * 16 + frow) * CS + wc * 64 + i * 16 + q4) = pk;
             }
-            uint2 pk;
-            pk.x = pack_bf16x2(v[0], v[1]);
-            pk.y = pack_bf16x2(v[2], v[3]);
-            *(uint2*)(cs + pix * CS + col) = pk;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int col = wc * 64 + i * 16 + q4;  // channel inside the block tile (4 consecutive)
+            float b[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[r] = a.bias[min(c0 + col + r, a.K - 1)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pix = wp * 64 + j * 16 + frow;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[i][j][r] + b[r];
+                    if (a.act == 1) t = fmaxf(t, 0.f);
+                    else if (a.act == 2) t = gelu_tanh(t);
+                    v[r] = t;
+                }
+                uint2 pk;
+                pk.x = pack_bf16x2(v[0], v[1]);
+                pk.y = pack_bf16x2(v[2], v[3]);
+                *(uint2*)(cs + pix * CS + col) = pk;
+            }
         }
     }
     __syncthreads();
 
-    // ---- optional BatchNorm statistics: per-channel (sum, sumsq) of the bf16-rounded tile,
-    //      added into replica (tile_p mod stats_rows) of a zero-initialised [rows][2][K] buffer.
-    //      One wave-instruction adds 64 consecutive floats (256 contiguous bytes). ----
+    // ---- optional BatchNorm statistics of the bf16-rounded tile, on the matrix cores: for a block
+    //      of 16 channels the transposed LDS read delivers F[c][p] (8 consecutive pixels per lane),
+    //      which is at once the A and the B fragment of G = F F^T (diagonal = sum of squares), and
+    //      F . ones gives the plain sums.  Two MFMAs per 16 channels x 32 pixels replace 1.5 k
+    //      LDS/VALU instructions per wave; the 16 diagonal lanes add (sum, sumsq) into replica
+    //      (tile_p mod stats_rows) of a zero-initialised [rows][2][K] buffer. ----
     if (a.stats != nullptr) {
-        const int col = tid % BC, grp = tid / BC;  // BC * WP == 256
-        float s = 0.f, q = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < 64; ++r) {
-            float v = bf16_to_float(cs[(grp * 64 + r) * CS + col]);
-            s += v; q += v * v;
-        }
-        if (c0 + col < a.K) {
-            float* dst = a.stats + (long)(tile_p % a.stats_rows) * 2 * a.K + c0 + col;
-            atomicAdd(dst, s);
-            atomicAdd(dst + a.K, q);
+        constexpr int CB_PER_WAVE = BC / 16 / 4;
+        const int kg = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+        bf16x8 ones;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+        const unsigned char* csb = (const unsigned char*)cs;
+#pragma unroll
+        for (int u = 0; u < CB_PER_WAVE; ++u) {
+            const int cb = wave * CB_PER_WAVE + u;
+            floatx4 G = {0.f, 0.f, 0.f, 0.f}, Sm = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int pb = 0; pb < BP / 32; ++pb) {
+                const int row = pb * 32 + 8 * kg + tq;
+                const unsigned char* ptr = csb + row * (CS * 2) + (cb * 16 + 4 * tp) * 2;
+                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(ptr));
+                const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(ptr + 4 * CS * 2));
+                const bf16x8 f = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                G = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, f, G, 0, 0, 0);
+                Sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, ones, Sm, 0, 0, 0);
+            }
+            // C layout: column n = lane & 15, rows 4 * (lane >> 4) + r; the diagonal element of channel
+            // n sits in the lane whose row group contains n, in register n & 3
+            const int r = li & 3;
+            const float q = r == 0 ? G[0] : r == 1 ? G[1] : r == 2 ? G[2] : G[3];
+            const float sm = r == 0 ? Sm[0] : r == 1 ? Sm[1] : r == 2 ? Sm[2] : Sm[3];
+            const int ch = c0 + cb * 16 + li;
+            if ((li >> 2) == kg && ch < a.K) {
+                float* dst = a.stats + (long)(tile_p % a.stats_rows) * 2 * a.K + ch;
+                atomicAdd(dst, sm);
+                atomicAdd(dst + a.K, q);
+            }
         }
     }
 
