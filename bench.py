@@ -36,7 +36,7 @@ def parse():
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--model", default="resnet50", choices=["resnet50", "resnet152", "gpt2", "mnist", "tiny_resnet"])
-    p.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 256 resnet50, 8 gpt2, 128/N mnist)")
+    p.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 256 resnet50, 128 resnet152, 8 gpt2, 128/N mnist)")
     p.add_argument("--seq-len", type=int, default=1024)
     p.add_argument("--bucket-mb", type=float, default=32.0)
     p.add_argument("--first-bucket-mb", type=float, default=4.0)
@@ -48,7 +48,7 @@ def parse():
     return p.parse_args()
 
 
-def load_baseline(model: str, n: int):
+def load_baseline(model: str, n: int, per_gpu_batch: int):
     """Stock PyTorch-ROCm numbers measured by scripts/baseline_torch.py on MI355X.
     The reference itself publishes none.  For N > 1 the comparison line is N x the measured
     1-GPU stock number (i.e. stock PyTorch given perfect scaling)."""
@@ -59,6 +59,8 @@ def load_baseline(model: str, n: int):
         with open(path) as f:
             data = json.load(f)
         entry = data.get(model, {})
+        if not isinstance(entry, dict) or ("batch" in entry and int(entry["batch"]) != per_gpu_batch):
+            return None          # the comparison line was measured at a different per-GPU batch
         if str(n) in entry:
             return float(entry[str(n)])
         if "1" in entry:
@@ -98,7 +100,7 @@ def main():
     else:
         if args.model in ("resnet50", "resnet152", "tiny_resnet"):
             from distributedpytorch_amd.models import resnet
-            batch = args.batch or 256
+            batch = args.batch or (128 if args.model == "resnet152" else 256)
             if args.model == "tiny_resnet":
                 model = resnet.tiny_resnet(); hw, classes = 64, 16
             else:
@@ -161,13 +163,15 @@ def main():
     if rank == 0:
         elapsed = result["elapsed"]
         value = result["items_per_rank_step"] * result.get("dp_world", world) * args.steps / elapsed
-        base = load_baseline(args.model, world)
+        pgb = result["config"].get("per_gpu_batch", 0)
+        base = load_baseline(args.model, world, pgb) if not (args.pipeline and args.pipeline > 1) else None
+        strong = args.model == "mnist" and not args.batch      # the reference's config fixes the GLOBAL batch at 128
         metric = "images/sec (whole node) ResNet-50 DP" if args.model == "resnet50" and not args.pipeline else \
             f"{unit} (whole job) {args.model}"
         out = {
             "metric": metric, "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": (round(value / base, 4) if base else None), "dtype": "bf16" if args.model != "mnist" else "fp32",
+            "scaling": "strong" if strong else "weak", "vs_baseline": (round(value / base, 4) if base else None), "dtype": "bf16" if args.model != "mnist" else "fp32",
             "data": "synthetic (random-init weights, on-device random inputs of the named shape)",
             "final_loss": result["loss"], "config": result["config"],
         }
