@@ -140,7 +140,11 @@ void colsum(const Tensor& x, Tensor& out) {
     const int64_t K = x.size(-1);
     TORCH_CHECK(K % 8 == 0 && out.numel() == K, "colsum: bad shapes");
     Guard g(x);
-    dpa::colsum_bf16(x.data_ptr(), out.data_ptr<float>(), x.numel() / K, K, cur_stream());
+    const int64_t M = x.numel() / K;
+    const int wr = dpa::colsum_workspace_rows(M, K);
+    Tensor ws;
+    if (wr > 0) ws = torch::empty({wr, K}, out.options());
+    dpa::colsum_bf16(x.data_ptr(), out.data_ptr<float>(), M, K, wr > 0 ? ws.data_ptr<float>() : nullptr, cur_stream());
 }
 
 // ---------------------------------------------------------------- batch norm

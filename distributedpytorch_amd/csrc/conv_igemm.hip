@@ -435,24 +435,44 @@ __global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __res
     }
 }
 
-__global__ __launch_bounds__(256) void colsum_wide_kernel(const unsigned short* __restrict__ x, float* __restrict__ out,
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const unsigned short* __restrict__ x, float* __restrict__ part,
                                                           long M, int K, long rows_per_block) {
-    // K/8 > 256: thread -> chunk (grid.y tiles the channels), loop rows
+    // wide matrices (K/8 > 256): thread -> 16-byte chunk (grid.y tiles the channels), 4 independent row
+    // streams per thread; every block writes its own partial row (no same-address atomics), folded afterwards
     const int ch = blockIdx.y * 256 + threadIdx.x;
     if (ch * 8 >= K) return;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    for (long r = r0; r < r1; ++r) {
-        uint4 v = *(const uint4*)(x + r * K + ch * 8);
+    const unsigned short* px = x + ch * 8;
+    long r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        uint4 v0 = *(const uint4*)(px + (r + 0) * K), v1 = *(const uint4*)(px + (r + 1) * K);
+        uint4 v2 = *(const uint4*)(px + (r + 2) * K), v3 = *(const uint4*)(px + (r + 3) * K);
+        float f0[8], f1[8], f2[8], f3[8];
+        unpack8(v0, f0); unpack8(v1, f1); unpack8(v2, f2); unpack8(v3, f3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += (f0[j] + f1[j]) + (f2[j] + f3[j]);
+    }
+    for (; r < r1; ++r) {
+        uint4 v = *(const uint4*)(px + r * K);
         float f[8]; unpack8(v, f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] += f[j];
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(out + ch * 8 + j, s[j]);
+    float* dst = part + (long)blockIdx.x * K + ch * 8;
+    *(float4*)(dst) = make_float4(s[0], s[1], s[2], s[3]);
+    *(float4*)(dst + 4) = make_float4(s[4], s[5], s[6], s[7]);
 }
 
-void colsum_bf16(const void* x, float* out, long M, int K, hipStream_t st) {
+int colsum_workspace_rows(long M, int K) {
+    if (K / 8 <= 256) return 0;
+    long b = (M + 31) / 32;
+    if (b > 256) b = 256;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+void colsum_bf16(const void* x, float* out, long M, int K, float* workspace, hipStream_t st) {
     const int cpr = K / 8;
     if (cpr <= 256) {
         int blocks = (int)min((long)512, (M + 63) / 64);
@@ -460,11 +480,11 @@ void colsum_bf16(const void* x, float* out, long M, int K, hipStream_t st) {
         long rpb = (M + blocks - 1) / blocks;
         hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, st, (const unsigned short*)x, out, M, K, rpb);
     } else {
-        int by = (cpr + 255) / 256;
-        int blocks = (int)min((long)128, (M + 63) / 64);
-        if (blocks < 1) blocks = 1;
-        long rpb = (M + blocks - 1) / blocks;
-        hipLaunchKernelGGL(colsum_wide_kernel, dim3(blocks, by), dim3(256), 0, st, (const unsigned short*)x, out, M, K, rpb);
+        const int by = (cpr + 255) / 256;
+        const int blocks = colsum_workspace_rows(M, K);
+        const long rpb = (M + blocks - 1) / blocks;
+        hipLaunchKernelGGL(colsum_wide_kernel, dim3(blocks, by), dim3(256), 0, st, (const unsigned short*)x, workspace, M, K, rpb);
+        reduce_partials(workspace, blocks, K, out, 1, st);   // out += column sums of the partial rows
     }
 }
 

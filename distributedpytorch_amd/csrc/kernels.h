@@ -47,7 +47,9 @@ void conv_wgrad(const WgradArgs& a, hipStream_t st);
 // [K, RS, C] bf16 -> [C, RS, K] bf16 (filter for dgrad)
 void transpose_filter(const void* w, void* wt, int K, int RS, int C, hipStream_t st);
 // column sums of a bf16 [M, K] matrix into fp32 [K] (bias gradient), accumulates.
-void colsum_bf16(const void* x, float* out, long M, int K, hipStream_t st);
+// wide matrices (K > 2048) need a [colsum_workspace_rows][K] fp32 scratch buffer
+int colsum_workspace_rows(long M, int K);
+void colsum_bf16(const void* x, float* out, long M, int K, float* workspace, hipStream_t st);
 
 // ---------------------------------------------------------------- batch norm (NHWC, rows = N*H*W)
 // partial (sum,sumsq) per block of rows -> stats[rows][2][C]

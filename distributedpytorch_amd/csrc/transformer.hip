@@ -192,7 +192,7 @@ inline int grid_for(long n) { long b = (n + 255) / 256; if (b > 4096) b = 4096; 
 
 int layernorm_partial_rows(long rows) {
     long b = (rows + 3) / 4;
-    if (b > 512) b = 512;
+    if (b > 256) b = 256;
     if (b < 1) b = 1;
     return (int)b;
 }
