@@ -40,6 +40,7 @@ def parse():
     p.add_argument("--seq-len", type=int, default=1024)
     p.add_argument("--bucket-mb", type=float, default=32.0)
     p.add_argument("--first-bucket-mb", type=float, default=4.0)
+    p.add_argument("--no-graph", action="store_true", help="mnist: do not capture forward+backward in a hipGraph")
     p.add_argument("--pipeline", type=int, default=0, help="number of pipeline stages (0 = pure data parallel)")
     p.add_argument("--micro-batches", type=int, default=8)
     p.add_argument("--schedule", default="1f1b")
@@ -138,10 +139,23 @@ def main():
         opt = FusedSGD(dp.flat, lr=lr, momentum=momentum, weight_decay=wd)
         opt.grad_scale = dp.grad_scale
 
+        graphed = None
+        if args.model == "mnist" and not args.no_graph:
+            # launch-bound regime: forward+backward replayed from one hipGraph (parallel/graph.py);
+            # the single gradient all-reduce and the fused optimizer kernel stay outside the graph
+            from distributedpytorch_amd.parallel.graph import GraphedStep
+            model._drop.use_device_counter(device)
+            graphed = GraphedStep(dp, lambda xx, yy: mnist.nll_loss(model(xx), yy), (x, y), after_backward=model._drop.advance)
+            cfg["hipgraph"] = True
+
         def step():
-            loss = loss_fn()
-            loss.backward()
-            dp.finish()
+            if graphed is not None:
+                loss = graphed(x, y)
+                dp.reduce_all()
+            else:
+                loss = loss_fn()
+                loss.backward()
+                dp.finish()
             opt.step()
             return loss
 

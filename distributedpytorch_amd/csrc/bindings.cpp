@@ -456,7 +456,7 @@ std::vector<Tensor> conv5_pool_relu_bwd(const Tensor& x, const Tensor& w, const 
     const float* dm = nullptr;
     if (drop.has_value() && drop->defined()) { CHECK_F32((*drop)); dm = drop->data_ptr<float>(); }
     Guard g(x);
-    Tensor dw = torch::empty_like(w), db = torch::empty({Cout}, w.options()), dx;
+    Tensor dw = torch::zeros_like(w), db = torch::zeros({Cout}, w.options()), dx;   // accumulated with atomics
     if (need_dx) dx = torch::empty_like(x);
     dpa::conv5_pool_relu_bwd(x.data_ptr<float>(), w.data_ptr<float>(), dy.data_ptr<float>(), y.data_ptr<float>(),
                              idx.data_ptr<uint8_t>(), need_dx ? dx.data_ptr<float>() : nullptr, dw.data_ptr<float>(),
@@ -514,12 +514,22 @@ Tensor nll_bwd(const Tensor& gout, const Tensor& t, int64_t rows, int64_t V) {
     dpa::nll_bwd(gout.data_ptr<float>(), t.data_ptr<int64_t>(), d.data_ptr<float>(), rows, V, cur_stream());
     return d;
 }
-Tensor dropout_mask(int64_t n, double p, int64_t seed, int64_t offset, const Tensor& like) {
+Tensor dropout_mask(int64_t n, double p, int64_t seed, int64_t offset, const Tensor& like, const c10::optional<Tensor>& step) {
     CHECK_DEV(like);
     Guard g(like);
     Tensor m = torch::empty({n}, like.options().dtype(at::kFloat));
-    dpa::dropout_mask(m.data_ptr<float>(), n, (float)p, (uint64_t)seed, (uint64_t)offset, cur_stream());
+    const int64_t* sp = nullptr;
+    if (step.has_value() && step->defined()) {
+        TORCH_CHECK(step->is_cuda() && step->scalar_type() == at::kLong && step->numel() == 1, "dropout_mask: step must be a device int64 scalar");
+        sp = step->data_ptr<int64_t>();
+    }
+    dpa::dropout_mask(m.data_ptr<float>(), n, (float)p, (uint64_t)seed, (uint64_t)offset, sp, cur_stream());
     return m;
+}
+void counter_add(Tensor& c, int64_t v) {
+    TORCH_CHECK(c.is_cuda() && c.scalar_type() == at::kLong && c.numel() == 1, "counter_add: device int64 scalar");
+    Guard g(c);
+    dpa::counter_add(c.data_ptr<int64_t>(), v, cur_stream());
 }
 Tensor mul_f32(const Tensor& a, const Tensor& b) {
     CHECK_F32(a); CHECK_F32(b); TORCH_CHECK(a.numel() == b.numel(), "mul: sizes");
@@ -566,6 +576,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("nll_fwd", &nll_fwd);
     m.def("nll_bwd", &nll_bwd);
     m.def("dropout_mask", &dropout_mask);
+    m.def("counter_add", &counter_add);
     m.def("mul_f32", &mul_f32);
     bind_transformer(m);
 }

@@ -283,8 +283,12 @@ __global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, c
 }
 
 // Philox-free counter hash RNG (splitmix64) for dropout masks: mask = (u >= p) / (1-p)
-__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ mask, long n, float p, uint64_t seed, uint64_t offset) {
+// `step` (optional): device-resident step counter, so a step captured in a hipGraph draws a fresh
+// mask at every replay (a host-side counter would be frozen into the graph).
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ mask, long n, float p, uint64_t seed, uint64_t offset,
+                                                           const int64_t* __restrict__ step) {
     const float keep_scale = 1.f / (1.f - p);
+    if (step != nullptr) offset += (uint64_t)step[0] * 2000003ull;
     GRID_STRIDE(i, n) {
         uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + offset + 1);
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -364,8 +368,12 @@ void scale_f32(float* x, long n, float s, hipStream_t st) {
 void mul_f32(const float* a, const float* b, float* y, long n, hipStream_t st) {
     hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, b, y, n);
 }
-void dropout_mask(float* mask, long n, float p, uint64_t seed, uint64_t offset, hipStream_t st) {
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, st, mask, n, p, seed, offset);
+void dropout_mask(float* mask, long n, float p, uint64_t seed, uint64_t offset, const int64_t* step, hipStream_t st) {
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, st, mask, n, p, seed, offset, step);
 }
+
+__global__ void counter_add_kernel(int64_t* c, int64_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += v; }
+
+void counter_add(int64_t* c, int64_t v, hipStream_t st) { hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, st, c, v); }
 
 }  // namespace dpa

@@ -143,7 +143,8 @@ void log_softmax_fwd(const float* x, float* y, int rows, int V, hipStream_t st);
 void log_softmax_bwd(const float* dy, const float* y, float* dx, int rows, int V, hipStream_t st);
 void nll_fwd(const float* logp, const int64_t* t, float* loss, int rows, int V, hipStream_t st);
 void nll_bwd(const float* g, const int64_t* t, float* dlogp, int rows, int V, hipStream_t st);
-void dropout_mask(float* mask, long n, float p, uint64_t seed, uint64_t offset, hipStream_t st);
+void dropout_mask(float* mask, long n, float p, uint64_t seed, uint64_t offset, const int64_t* step, hipStream_t st);
+void counter_add(int64_t* c, int64_t v, hipStream_t st);   // device-resident step counter (graph-replay safe)
 void mul_f32(const float* a, const float* b, float* y, long n, hipStream_t st);
 
 }  // namespace dpa

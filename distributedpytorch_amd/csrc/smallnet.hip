@@ -60,7 +60,9 @@ __device__ __forceinline__ float pooled_grad(const float* dy, const float* y, co
     return g;
 }
 
-// dw: one block per (co, ci); threads stride over (n, ph, pw); 25 accumulators per thread
+// dw: blockIdx.x = (co, ci), blockIdx.y = slice of the (n, ph, pw) cells; 25 accumulators per thread, block
+// reduction, then one atomic per filter tap into the zero-initialised dw / db (a 10-filter layer would
+// otherwise run on 10 workgroups of a 256-CU chip)
 __global__ __launch_bounds__(256) void conv5_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                        const float* __restrict__ y, const uint8_t* __restrict__ idx,
                                                        float* __restrict__ dw, float* __restrict__ db, int N, int Cin,
@@ -72,10 +74,11 @@ __global__ __launch_bounds__(256) void conv5_dw_kernel(const float* __restrict__
     for (int k = 0; k < KS * KS; ++k) acc[k] = 0.f;
     float bsum = 0.f;
     const int cells = N * PH * PW;
-    for (int c = threadIdx.x; c < cells; c += 256) {
+    const int per = (cells + gridDim.y - 1) / gridDim.y;
+    const int c0 = blockIdx.y * per, c1 = min(cells, c0 + per);
+    for (int c = c0 + threadIdx.x; c < c1; c += 256) {
         const int pw = c % PW; int t = c / PW; const int ph = t % PH; const int n = t / PH;
         const long i = (((long)n * Cout + co) * PH + ph) * PW + pw;
-        // dropped channels can still have y == 0 -> g == 0, fine
         float g = dy[i];
         if (drop != nullptr) { const float dm = drop[n * Cout + co]; g = (y[i] > 0.f) ? g * dm : 0.f; }
         else g = (y[i] > 0.f) ? g : 0.f;
@@ -101,9 +104,68 @@ __global__ __launch_bounds__(256) void conv5_dw_kernel(const float* __restrict__
     }
     __syncthreads();
     if (threadIdx.x < KS * KS)
-        dw[((long)co * Cin + ci) * KS * KS + threadIdx.x] =
-            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    if (threadIdx.x == 0 && ci == 0) db[co] = red[0][KS * KS] + red[1][KS * KS] + red[2][KS * KS] + red[3][KS * KS];
+        atomicAdd(dw + ((long)co * Cin + ci) * KS * KS + threadIdx.x,
+                  red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x == 0 && ci == 0) atomicAdd(db + co, red[0][KS * KS] + red[1][KS * KS] + red[2][KS * KS] + red[3][KS * KS]);
+}
+
+// dx, LDS-tiled, shapes fixed at compile time (the reference's conv2: 10 -> 20 channels on 12x12): one
+// workgroup per sample.  The sample's conv-output gradient is scattered into a ZERO-PADDED dense
+// [Cout][OH+8][OW+8] LDS image (non-zero only at the pooling arg-max positions; the padding makes every
+// filter tap in range, so the hot loop has no conditions), the layer's filters sit in LDS as well, and
+// each thread produces one input ROW (ci, h, 0..W-1) in registers: per (co, r) it reads one padded
+// gradient row (4 x ds_read_b128) and five taps for 5*W FMAs of straight-line code.
+template <int CIN, int COUT, int HH, int WW>
+__global__ __launch_bounds__(256) void conv5_dx_tiled_kernel(const float* __restrict__ w, const float* __restrict__ dy,
+                                                             const float* __restrict__ y, const uint8_t* __restrict__ idx,
+                                                             float* __restrict__ dx, const float* __restrict__ drop) {
+    constexpr int OH = HH - KS + 1, OW = WW - KS + 1, PH = OH / 2, PW = OW / 2;
+    constexpr int GH = OH + 2 * (KS - 1), GW = (OW + 2 * (KS - 1) + 3) / 4 * 4;    // padded image, rows 16-byte multiples
+    static_assert(GW >= WW + KS - 1, "padded row must cover every tap of every output column");
+    __shared__ __attribute__((aligned(16))) float G[COUT * GH * GW];
+    __shared__ __attribute__((aligned(16))) float Wl[COUT * CIN * KS * KS];
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < COUT * GH * GW; i += 256) G[i] = 0.f;
+    for (int i = threadIdx.x; i < COUT * CIN * KS * KS; i += 256) Wl[i] = w[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < COUT * PH * PW; i += 256) {
+        const int pw = i % PW; int t = i / PW; const int ph = t % PH; const int co = t / PH;
+        const long o = (long)n * COUT * PH * PW + i;
+        float g = y[o] > 0.f ? dy[o] : 0.f;
+        if (drop != nullptr) g *= drop[n * COUT + co];
+        const int bi = idx[o];
+        G[(co * GH + ph * 2 + (bi >> 1) + KS - 1) * GW + pw * 2 + (bi & 1) + KS - 1] = g;
+    }
+    __syncthreads();
+    const int row = threadIdx.x;
+    if (row >= CIN * HH) return;
+    const int ci = row / HH, h = row - ci * HH;
+    float acc[WW];
+#pragma unroll
+    for (int v = 0; v < WW; ++v) acc[v] = 0.f;
+    for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+        for (int r = 0; r < KS; ++r) {
+            // dx[h][v] += sum_s G[h - r][v - s] * w[r][s];  padded coordinates: row h - r + 4, column v - s + 4
+            const float4* gp4 = (const float4*)(G + (co * GH + h - r + KS - 1) * GW);
+            float gr[GW];
+#pragma unroll
+            for (int q = 0; q < GW / 4; ++q) {
+                const float4 t4 = gp4[q];
+                gr[4 * q] = t4.x; gr[4 * q + 1] = t4.y; gr[4 * q + 2] = t4.z; gr[4 * q + 3] = t4.w;
+            }
+            const float* wp = Wl + ((co * CIN + ci) * KS + r) * KS;
+#pragma unroll
+            for (int sft = 0; sft < KS; ++sft) {
+                const float wv = wp[sft];
+#pragma unroll
+                for (int v = 0; v < WW; ++v) acc[v] += gr[v - sft + KS - 1] * wv;
+            }
+        }
+    }
+    float* dst = dx + (((long)n * CIN + ci) * HH + h) * WW;
+#pragma unroll
+    for (int v = 0; v < WW; ++v) dst[v] = acc[v];
 }
 
 // dx: one thread per input element; walks the (co, r, s) taps and keeps those that hit an arg-max
@@ -179,43 +241,44 @@ __global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict_
     }
 }
 
-// dw[o][k] = sum_r g[r][o] * x[r][k] ; db[o] = sum_r g[r][o].  one block per o, threads over k, rows serial in chunks
+// dw[o][k] = sum_r g[r][o] * x[r][k] ; db[o] = sum_r g[r][o].  Block = (o, 64-wide k tile); the 4 waves take
+// interleaved rows (8 independent loads in flight per thread - the loop is latency-bound, not
+// bandwidth-bound) and are folded through LDS.  x rows are read coalesced over k; g[r][o] is a broadcast.
 __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                         const float* __restrict__ dy, float* __restrict__ dw,
                                                         float* __restrict__ db, int rows, int in, int out, int relu) {
-    const int o = blockIdx.x;
-    // threads: (k lane, row lane)
-    const int kl = in < 256 ? in : 256;            // active k lanes per pass
-    const int rlanes = 256 / kl;                   // row lanes (>= 1)
-    __shared__ float red[256];
-    for (int k0 = 0; k0 < in; k0 += kl) {
-        const int k = k0 + threadIdx.x % kl, rl = threadIdx.x / kl;
-        float acc = 0.f;
-        if (rl < rlanes && k < in)
-            for (int r = rl; r < rows; r += rlanes) {
-                float g = dy[(long)r * out + o];
-                if (relu && !(y[(long)r * out + o] > 0.f)) g = 0.f;
-                acc += g * x[(long)r * in + k];
-            }
-        red[threadIdx.x] = acc;
-        __syncthreads();
-        if (threadIdx.x < kl && k0 + threadIdx.x < in) {
-            float s = 0.f;
-            for (int l = 0; l < rlanes; ++l) s += red[l * kl + threadIdx.x];
-            dw[(long)o * in + k0 + threadIdx.x] = s;
+    const int ktiles = (in + 63) / 64;
+    const int o = blockIdx.x / ktiles, k = (blockIdx.x % ktiles) * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const bool kok = k < in;
+    float acc = 0.f, bs = 0.f;
+    int r = rg;
+    for (; r + 28 < rows; r += 32) {
+        float g[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long rr = r + 4 * u;
+            g[u] = dy[rr * out + o];
+            if (relu && !(y[rr * out + o] > 0.f)) g[u] = 0.f;
+            xv[u] = kok ? x[rr * in + k] : 0.f;
         }
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc += g[u] * xv[u]; bs += g[u]; }
     }
-    float bs = 0.f;
-    for (int r = threadIdx.x; r < rows; r += 256) {
+    for (; r < rows; r += 4) {
         float g = dy[(long)r * out + o];
         if (relu && !(y[(long)r * out + o] > 0.f)) g = 0.f;
+        acc += g * (kok ? x[(long)r * in + k] : 0.f);
         bs += g;
     }
-    bs = wave_reduce_sum(bs);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bs;
+    __shared__ float red[2][4][64];
+    red[0][rg][threadIdx.x & 63] = acc;
+    red[1][rg][threadIdx.x & 63] = bs;
     __syncthreads();
-    if (threadIdx.x == 0 && db != nullptr) db[o] = red[0] + red[1] + red[2] + red[3];
+    if (rg == 0) {
+        const int l = threadIdx.x;
+        if (kok) dw[(long)o * in + k] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+        if (l == 0 && blockIdx.x % ktiles == 0 && db != nullptr) db[o] = red[1][0][0] + red[1][1][0] + red[1][2][0] + red[1][3][0];
+    }
 }
 
 // log_softmax over rows of a small [rows, V] fp32 matrix: one wave per row
@@ -279,10 +342,20 @@ void conv5_pool_relu_fwd(const float* x, const float* w, const float* b, float* 
 void conv5_pool_relu_bwd(const float* x, const float* w, const float* dy, const float* y, const uint8_t* idx,
                          float* dx, float* dw, float* db, int N, int Cin, int H, int W, int Cout,
                          const float* drop_mask, hipStream_t st) {
-    hipLaunchKernelGGL(conv5_dw_kernel, dim3(Cout * Cin), dim3(256), 0, st, x, dy, y, idx, dw, db, N, Cin, H, W, Cout, drop_mask);
-    if (dx != nullptr)
-        hipLaunchKernelGGL(conv5_dx_kernel, dim3(grid_for((long)N * Cin * H * W)), dim3(256), 0, st, w, dy, y, idx, dx, N, Cin,
-                           H, W, Cout, drop_mask);
+    // dw / db are accumulated with atomics: the caller passes them zero-initialised
+    const int PH = (H - KS + 1) / 2, PW = (W - KS + 1) / 2;
+    const int cells = N * PH * PW;
+    int split = 512 / (Cout * Cin);
+    if (split > (cells + 255) / 256) split = (cells + 255) / 256;
+    if (split < 1) split = 1;
+    hipLaunchKernelGGL(conv5_dw_kernel, dim3(Cout * Cin, split), dim3(256), 0, st, x, dy, y, idx, dw, db, N, Cin, H, W, Cout, drop_mask);
+    if (dx != nullptr) {
+        if (Cin == 10 && Cout == 20 && H == 12 && W == 12)   // the reference's conv2 (DP.py:83)
+            hipLaunchKernelGGL((conv5_dx_tiled_kernel<10, 20, 12, 12>), dim3(N), dim3(256), 0, st, w, dy, y, idx, dx, drop_mask);
+        else
+            hipLaunchKernelGGL(conv5_dx_kernel, dim3(grid_for((long)N * Cin * H * W)), dim3(256), 0, st, w, dy, y, idx, dx, N, Cin,
+                               H, W, Cout, drop_mask);
+    }
 }
 
 void linear_f32_fwd(const float* x, const float* w, const float* b, float* y, int rows, int in, int out, int relu, hipStream_t st) {
@@ -293,7 +366,7 @@ void linear_f32_bwd(const float* x, const float* w, const float* y, const float*
                     int rows, int in, int out, int relu, hipStream_t st) {
     if (dx != nullptr)
         hipLaunchKernelGGL(linear_dx_kernel, dim3(grid_for((long)rows * in)), dim3(256), 0, st, w, y, dy, dx, rows, in, out, relu);
-    hipLaunchKernelGGL(linear_dw_kernel, dim3(out), dim3(256), 0, st, x, y, dy, dw, db, rows, in, out, relu);
+    hipLaunchKernelGGL(linear_dw_kernel, dim3((unsigned)(out * ((in + 63) / 64))), dim3(256), 0, st, x, y, dy, dw, db, rows, in, out, relu);
 }
 
 void log_softmax_fwd(const float* x, float* y, int rows, int V, hipStream_t st) {

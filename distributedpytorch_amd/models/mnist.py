@@ -18,14 +18,29 @@ from .. import ops
 
 
 class _DropState:
-    """Counter-based dropout stream: masks are a pure function of (seed, step, layer)."""
+    """Counter-based dropout stream: masks are a pure function of (seed, step, layer).
+
+    Eager mode counts steps on the host.  ``use_device_counter`` moves the step counter into
+    device memory (bumped by a one-thread kernel, ``advance()``), so a training step captured in
+    a hipGraph still draws fresh masks at every replay."""
 
     def __init__(self, seed: int = 1234):
         self.seed, self.step = seed, 0
+        self.dev_step = None
 
-    def next(self) -> int:
+    def use_device_counter(self, device) -> None:
+        self.dev_step = torch.zeros(1, dtype=torch.int64, device=device)
+
+    def next(self, layer: int) -> int:
+        if self.dev_step is not None:
+            return layer * 1_000_003          # the device counter supplies the step term
         self.step += 1
-        return self.step
+        return self.step * 1_000_003 + layer
+
+    def advance(self) -> None:
+        if self.dev_step is not None:
+            from ..ops import _ext
+            _ext.load().counter_add(self.dev_step, 1)
 
 
 class Net(nn.Module):
@@ -45,14 +60,14 @@ class Net(nn.Module):
         mask = None
         if self.training and self.conv2_drop.p > 0:
             mask = ops.channel_dropout_mask(x.shape[0], 20, self.conv2_drop.p, x, self._drop.seed,
-                                            self._drop.next() * 1_000_003)
+                                            self._drop.next(0), self._drop.dev_step)
         x = ops.conv5_pool_relu(x, self.conv2.weight, self.conv2.bias, mask)
         return x.reshape(-1, 320)
 
     def logits(self, x: torch.Tensor) -> torch.Tensor:
         x = self.features(x)
         x = ops.linear_f32(x, self.fc1.weight, self.fc1.bias, relu=True)
-        x = ops.dropout(x, 0.5, self.training, self._drop.seed, self._drop.next() * 1_000_003 + 7)
+        x = ops.dropout(x, 0.5, self.training, self._drop.seed, self._drop.next(7), self._drop.dev_step)
         return ops.linear_f32(x, self.fc2.weight, self.fc2.bias)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

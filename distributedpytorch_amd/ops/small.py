@@ -33,10 +33,12 @@ class _Conv5PoolReluFn(torch.autograd.Function):
         return (dx if ctx.needs_input_grad[0] else None), dw, db, None
 
 
-def channel_dropout_mask(n: int, c: int, p: float, like: torch.Tensor, seed: int, offset: int) -> torch.Tensor:
-    """``[n*c]`` mask of 0 or 1/(1-p): one Bernoulli per (sample, channel) = ``Dropout2d``."""
+def channel_dropout_mask(n: int, c: int, p: float, like: torch.Tensor, seed: int, offset: int,
+                         step: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``[n*c]`` mask of 0 or 1/(1-p): one Bernoulli per (sample, channel) = ``Dropout2d``.
+    ``step``: device int64 step counter added to the stream position (hipGraph-replay safe)."""
     if like.is_cuda:
-        return _ext.load().dropout_mask(n * c, p, seed, offset, like)
+        return _ext.load().dropout_mask(n * c, p, seed, offset, like, step)
     g = torch.Generator().manual_seed(seed * 1000003 + offset)
     return (torch.rand(n * c, generator=g) >= p).float() / (1.0 - p)
 
@@ -87,12 +89,13 @@ class _DropoutFn(torch.autograd.Function):
         return _ext.load().mul_f32(dy.contiguous(), mask).view(dy.shape), None
 
 
-def dropout(x: torch.Tensor, p: float, training: bool, seed: int, offset: int) -> torch.Tensor:
+def dropout(x: torch.Tensor, p: float, training: bool, seed: int, offset: int,
+            step: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Element dropout (reference DP.py:93) with a counter-based mask generated on device."""
     if not training or p == 0.0:
         return x
     if _ext.use_hip(x):
-        mask = _ext.load().dropout_mask(x.numel(), p, seed, offset, x)
+        mask = _ext.load().dropout_mask(x.numel(), p, seed, offset, x, step)
         return _DropoutFn.apply(x.contiguous(), mask)
     g = torch.Generator().manual_seed(seed * 1000003 + offset)
     mask = (torch.rand(x.numel(), generator=g) >= p).float().view(x.shape) / (1.0 - p)

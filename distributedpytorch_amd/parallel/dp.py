@@ -136,6 +136,16 @@ class DataParallel:
                 b.work.wait()
         self._armed = False
 
+    def reduce_all(self) -> None:
+        """All-reduce every bucket now (no overlap).  For steps replayed from a hipGraph: no Python
+        hook fires during a replay, so the engine launches the buckets itself afterwards."""
+        self._arm()
+        for b in self.buckets:
+            self._launch(b)
+        for b in self._launched:
+            b.work.wait()
+        self._armed = False
+
     def average_gradients(self) -> None:
         """Reference-shaped API (DP.py:118-129): reduce everything now, blocking, and scale."""
         self.finish()

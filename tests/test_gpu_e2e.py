@@ -108,3 +108,41 @@ def test_gpt2_tiny_trains_on_gpu():
     losses, _, _ = _train(m, tok, tgt, 10, lr=0.02)
     assert abs(losses[0] - lref) < 0.05, (losses[0], lref)
     assert losses[-1] < losses[0]
+
+
+def test_mnist_hipgraph_step_matches_eager_and_draws_fresh_masks():
+    """Forward+backward captured in a hipGraph: gradients equal the eager step's (same device-counter
+    dropout stream), and a second replay draws different dropout masks."""
+    from distributedpytorch_amd.models import mnist
+    from distributedpytorch_amd.parallel.dp import DataParallel
+    from distributedpytorch_amd.parallel.graph import GraphedStep
+    from distributedpytorch_amd.data import synthetic_batch
+    x, y = synthetic_batch("mnist", 64, DEV, seed=5)
+
+    def build():
+        torch.manual_seed(1234)
+        m = mnist.Net().to(DEV).train()
+        m._drop.use_device_counter(DEV)
+        return m, DataParallel(m, use_lp=False)
+
+    m1, dp1 = build()
+    grads_eager = []
+    for _ in range(2):
+        dp1.flat.grad.zero_()
+        with dp1.no_sync():
+            mnist.nll_loss(m1(x), y).backward()
+        m1._drop.advance()
+        grads_eager.append(dp1.flat.grad.clone())
+    m2, dp2 = build()
+    g = GraphedStep(dp2, lambda a, b: mnist.nll_loss(m2(a), b), (x, y), after_backward=m2._drop.advance, warmup=2)
+    m2._drop.dev_step.zero_()                       # the warm-up advanced the counter; restart the stream
+    grads_graph = []
+    for _ in range(2):
+        dp2.flat.grad.zero_()
+        loss = g(x, y)
+        grads_graph.append(dp2.flat.grad.clone())
+    assert torch.isfinite(loss).all()
+    for a, b in zip(grads_eager, grads_graph):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+    assert not torch.equal(grads_graph[0], grads_graph[1])     # fresh dropout masks per replay
+    assert int(m2._drop.dev_step.item()) == 2
