@@ -41,7 +41,7 @@ def _data(shape, classes, n, seed=7):
     return torch.randn(n, *shape, generator=g), torch.randint(0, classes, (n,), generator=g)
 
 
-def dp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, bucket_kb, steps):
+def dp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, bucket_kb, steps, mode="hooks"):
     """Each rank takes its shard of ONE global batch; writes reduced grads + params."""
     comm = dcomm.init_process_group("gloo", url, global_rank, world_size, 60.0, torch.device("cpu"))
     model, loss_fn, shape, classes = _make_model(model_name)
@@ -54,9 +54,15 @@ def dp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, buc
     opt.grad_scale = dp.grad_scale
     losses = []
     for s in range(steps):
-        loss = loss_fn(model, xs, ys)
-        loss.backward()
-        dp.finish()
+        if mode == "reduce_all":            # the hipGraph-replay flow: no hook-driven launches, reduce afterwards
+            with dp.no_sync():
+                loss = loss_fn(model, xs, ys)
+                loss.backward()
+            dp.reduce_all()
+        else:
+            loss = loss_fn(model, xs, ys)
+            loss.backward()
+            dp.finish()
         if s == 0:
             g = dp.flat.grad.clone() * dp.grad_scale
             torch.save({n: g[dp.flat.offsets[i]:dp.flat.offsets[i] + p.numel()].view(p.shape).clone()

@@ -23,10 +23,11 @@ def _reference_mean_grads(model_name, world):
     return {n: v / world for n, v in acc.items()}
 
 
-@pytest.mark.parametrize("model_name,world,bucket_kb", [("mnist", 2, 1024), ("mnist", 4, 8), ("tiny_resnet", 2, 16)])
-def test_dp_gradients_are_the_mean_and_replicas_agree(tmp_path, model_name, world, bucket_kb):
+@pytest.mark.parametrize("model_name,world,bucket_kb,mode", [("mnist", 2, 1024, "hooks"), ("mnist", 4, 8, "hooks"),
+                                                             ("tiny_resnet", 2, 16, "hooks"), ("mnist", 2, 1024, "reduce_all")])
+def test_dp_gradients_are_the_mean_and_replicas_agree(tmp_path, model_name, world, bucket_kb, mode):
     url = f"tcp://127.0.0.1:{T.free_port()}"
-    launch.spawn(T.dp_worker, [world], 0, args=(url, model_name, str(tmp_path), bucket_kb, 4))
+    launch.spawn(T.dp_worker, [world], 0, args=(url, model_name, str(tmp_path), bucket_kb, 4, mode))
     ref = _reference_mean_grads(model_name, world)
     grads = [torch.load(tmp_path / f"grads_{r}.pt", weights_only=True) for r in range(world)]
     for name, g in ref.items():
