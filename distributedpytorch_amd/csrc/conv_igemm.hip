@@ -26,6 +26,7 @@
 // (+ k*stride), so each class is a dense small convolution and no MFMA work is spent on
 // structurally-zero taps (a masked stride-2 3x3 dgrad would waste 75 % of it; a strided
 // 1x1 dgrad is one dense GEMM on a quarter of the pixels plus zero fill).
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -43,10 +44,13 @@ __device__ __forceinline__ int swz4(int row) {  // conflict-free chunk swizzle f
 }
 
 // ONE: 1x1 filter, no padding (a plain GEMM over gathered rows): no tap arithmetic in the loop.
-// Register budget: 3 waves per SIMD (<= 168 VGPRs, accumulators stay in VGPRs - no AGPR copies);
-// the 256x64 general-gather variant needs a few more and runs at 2.
-template <int WP, int WC, int MODE, bool ONE>
-__global__ __launch_bounds__(256, (WP == 4 && !ONE) ? 2 : 3) void conv_igemm_kernel(ConvArgs a, int tiles_c, long M_all, int Kg_all) {
+// Two pipelining variants.  RING: two register sets, loads two tiles ahead, 3 waves per SIMD (<= 168
+// VGPRs; the 256x64 general-gather variant runs at 2).  !RING: one register set (write tile t+1 right
+// after the barrier, re-issue t+2 at once), <= 128 VGPRs = 4 waves per SIMD: better for grids of very
+// many short workgroups, where occupancy hides more than prefetch depth does (use_ring() below).
+// Accumulators stay in VGPRs in both (no AGPR copies).
+template <int WP, int WC, int MODE, bool ONE, bool RING>
+__global__ __launch_bounds__(256, RING ? ((WP == 4 && !ONE) ? 2 : 3) : 4) void conv_igemm_kernel(ConvArgs a, int tiles_c, long M_all, int Kg_all) {
     constexpr int BP = WP * 64, BC = WC * 64;
     constexpr int XR = BP * CHUNKS / 256;  // x rows per thread
     constexpr int WR = BC * CHUNKS / 256;  // w rows per thread
@@ -205,25 +209,39 @@ __global__ __launch_bounds__(256, (WP == 4 && !ONE) ? 2 : 3) void conv_igemm_ker
 
     // Loads past the last K tile fall outside the buffers (zeros) and their LDS image is never
     // read, so the loop body carries no conditions.
-    DPA_LOAD_TILE(xr0, wr0)
-    DPA_LOAD_TILE(xr1, wr1)
-    DPA_STORE_TILE(0, xr0, wr0)
-    __syncthreads();
-    for (int kt = 0; kt + 1 < nk; kt += 2) {
-        DPA_LOAD_TILE(xr0, wr0)            // tile kt + 2
-        __builtin_amdgcn_sched_barrier(0); // keep the loads ahead of the MFMAs and of the older tile's LDS writes
-        DPA_COMPUTE(0)                     // tile kt
-        DPA_STORE_TILE(1, xr1, wr1)        // tile kt + 1
+    if (RING) {
+        DPA_LOAD_TILE(xr0, wr0)
+        DPA_LOAD_TILE(xr1, wr1)
+        DPA_STORE_TILE(0, xr0, wr0)
         __syncthreads();
-        DPA_LOAD_TILE(xr1, wr1)            // tile kt + 3
-        __builtin_amdgcn_sched_barrier(0);
-        DPA_COMPUTE(1)                     // tile kt + 1
-        DPA_STORE_TILE(0, xr0, wr0)        // tile kt + 2
+        for (int kt = 0; kt + 1 < nk; kt += 2) {
+            DPA_LOAD_TILE(xr0, wr0)            // tile kt + 2
+            __builtin_amdgcn_sched_barrier(0); // keep the loads ahead of the MFMAs and of the older tile's LDS writes
+            DPA_COMPUTE(0)                     // tile kt
+            DPA_STORE_TILE(1, xr1, wr1)        // tile kt + 1
+            __syncthreads();
+            DPA_LOAD_TILE(xr1, wr1)            // tile kt + 3
+            __builtin_amdgcn_sched_barrier(0);
+            DPA_COMPUTE(1)                     // tile kt + 1
+            DPA_STORE_TILE(0, xr0, wr0)        // tile kt + 2
+            __syncthreads();
+        }
+        if (nk & 1) {
+            DPA_COMPUTE(0)
+            __syncthreads();
+        }
+    } else {
+        DPA_LOAD_TILE(xr0, wr0)
+        DPA_STORE_TILE(0, xr0, wr0)
+        DPA_LOAD_TILE(xr0, wr0)                // tile 1 in flight across the barrier
         __syncthreads();
-    }
-    if (nk & 1) {
-        DPA_COMPUTE(0)
-        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            DPA_STORE_TILE((kt + 1) & 1, xr0, wr0)   // tile kt + 1 (its buffer was last read before the barrier)
+            DPA_LOAD_TILE(xr0, wr0)                   // tile kt + 2
+            __builtin_amdgcn_sched_barrier(0);
+            DPA_COMPUTE(kt & 1)
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: bias/activation, stage the bf16 tile in LDS ----
@@ -351,7 +369,7 @@ __global__ __launch_bounds__(256, (WP == 4 && !ONE) ? 2 : 3) void conv_igemm_ker
 #undef DPA_STORE_TILE
 #undef DPA_COMPUTE
 
-template <int WP, int WC, bool ONE>
+template <int WP, int WC, bool ONE, bool RING>
 void launch(const ConvArgs& a, hipStream_t st) {
     const long M = (long)a.N * a.Ho * a.Wo;
     const int Kg = a.R * a.S * a.C;
@@ -359,15 +377,15 @@ void launch(const ConvArgs& a, hipStream_t st) {
     dim3 block(256);
     if (a.mode == 0) {
         const int tiles_p = (int)((M + WP * 64 - 1) / (WP * 64));
-        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 0, ONE>), dim3(tiles_p * tiles_c), block, 0, st, a, tiles_c, M, Kg);
+        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 0, ONE, RING>), dim3(tiles_p * tiles_c), block, 0, st, a, tiles_c, M, Kg);
     } else if (a.stride == 1) {
         const int tiles_p = (int)((M + WP * 64 - 1) / (WP * 64));
-        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 1, ONE>), dim3(tiles_p * tiles_c), block, 0, st, a, tiles_c, M, Kg);
+        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 1, ONE, RING>), dim3(tiles_p * tiles_c), block, 0, st, a, tiles_c, M, Kg);
     } else {
         const int st_ = a.stride;
         const long mc = (long)a.N * ((a.Ho + st_ - 1) / st_) * ((a.Wo + st_ - 1) / st_);   // largest parity class
         const int tiles_p = (int)((mc + WP * 64 - 1) / (WP * 64));
-        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 2, false>), dim3(tiles_p * tiles_c, st_ * st_), block, 0, st, a, tiles_c, M, Kg);
+        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 2, false, RING>), dim3(tiles_p * tiles_c, st_ * st_), block, 0, st, a, tiles_c, M, Kg);
     }
 }
 
@@ -375,11 +393,32 @@ void launch(const ConvArgs& a, hipStream_t st) {
 
 int conv_stats_rows(long M) { (void)M; return 32; }
 
+// DPA_IGEMM_RING=0/1 forces a variant (experiments); default: by resident-workgroup arithmetic.
+static bool use_ring(const ConvArgs& a) {
+    static const int forced = [] { const char* e = getenv("DPA_IGEMM_RING"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced != 0;
+    const long M = (long)a.N * a.Ho * a.Wo;
+    const bool wide = a.K <= 64;
+    const long bp = wide ? 256 : 128, bc = wide ? 64 : 128;
+    long blocks = ((M + bp - 1) / bp) * ((a.K + bc - 1) / bc);
+    if (a.mode != 0 && a.stride > 1) blocks /= (a.stride * a.stride);   // per parity class
+    // Measured on the ResNet-50 shapes (scripts/bench_conv.py, DPA_IGEMM_RING=0/1): grids of many short
+    // workgroups (layer-1 sized, >= ~16 per CU) gain 5-10 % from the 4th resident wave, long-K grids with
+    // few workgroups per CU lose up to 15 % without the deeper prefetch.
+    return blocks < 4096;
+}
+
 void conv_igemm(const ConvArgs& a, hipStream_t st) {
     // 1x1 / no padding: plain GEMM gather (strided fprop included; strided dgrad goes by parity class)
     const bool one = a.R == 1 && a.S == 1 && a.pad == 0 && (a.mode == 0 || a.stride == 1);
-    if (a.K <= 64) { if (one) launch<4, 1, true>(a, st); else launch<4, 1, false>(a, st); }
-    else           { if (one) launch<2, 2, true>(a, st); else launch<2, 2, false>(a, st); }
+    const bool ring = use_ring(a);
+    if (a.K <= 64) {
+        if (one) { if (ring) launch<4, 1, true, true>(a, st); else launch<4, 1, true, false>(a, st); }
+        else     { if (ring) launch<4, 1, false, true>(a, st); else launch<4, 1, false, false>(a, st); }
+    } else {
+        if (one) { if (ring) launch<2, 2, true, true>(a, st); else launch<2, 2, true, false>(a, st); }
+        else     { if (ring) launch<2, 2, false, true>(a, st); else launch<2, 2, false, false>(a, st); }
+    }
 }
 
 // ------------------------------------------------------------------ filter transpose
