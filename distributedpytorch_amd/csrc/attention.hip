@@ -46,6 +46,19 @@ __device__ __forceinline__ void load_tile(const unsigned short* __restrict__ g, 
     }
 }
 
+// the same load split in two, so the next tile's global loads are in flight under the current tile's
+// MFMAs: fetch_tile issues them into registers, stash_tile writes the registers to the LDS image
+__device__ __forceinline__ void fetch_tile(const unsigned short* __restrict__ g, long rs, int tid, u32x4 (&r)[2]) {
+    const int c = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) r[i] = *(const u32x4*)(g + (long)((tid >> 3) + i * 32) * rs + c * 8);
+}
+__device__ __forceinline__ void stash_tile(unsigned char* lds, int tid, const u32x4 (&r)[2]) {
+    const int c = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *(u32x4*)(lds + img_off((tid >> 3) + i * 32, c * 8)) = r[i];
+}
+
 // MFMA A/B row fragment: 8 consecutive d of one row (k = 8h + j + 16kk)
 __device__ __forceinline__ bf16x8 row_frag(const unsigned char* lds, int row, int kk, int h) {
     return *(const bf16x8*)(lds + img_off(row, 16 * kk + 8 * h));
@@ -113,11 +126,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const unsigned short* __r
     zero16(O[0]); zero16(O[1]);
     float m = NEG_BIG, l = 0.f;
     const int ntiles = (q0 + 128) / TILE;
+    u32x4 pk[2], pv[2];
+    fetch_tile(kbase, rs, tid, pk);
+    fetch_tile(vbase, rs, tid, pv);
     for (int j = 0; j < ntiles; ++j) {
         __syncthreads();
-        load_tile(kbase + (long)j * TILE * rs, rs, Ks, tid);
-        load_tile(vbase + (long)j * TILE * rs, rs, Vs, tid);
+        stash_tile(Ks, tid, pk);
+        stash_tile(Vs, tid, pv);
         __syncthreads();
+        if (j + 1 < ntiles) {
+            fetch_tile(kbase + (long)(j + 1) * TILE * rs, rs, tid, pk);
+            fetch_tile(vbase + (long)(j + 1) * TILE * rs, rs, tid, pv);
+        }
         if (j * TILE > qw0 + 31) continue;                       // wave-uniform: every key is in the future
         floatx16 S[2];
 #pragma unroll
@@ -223,12 +243,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const unsigned short* 
     floatx16 dKt[2], dVt[2];
     zero16(dKt[0]); zero16(dKt[1]); zero16(dVt[0]); zero16(dVt[1]);
 
+    u32x4 pq[2], po[2];
+    fetch_tile(base + (long)(k0 / TILE) * TILE * rs, rs, tid, pq);
+    fetch_tile(dobase + (long)(k0 / TILE) * TILE * ors, ors, tid, po);
     for (int jq = k0 / TILE; jq < T / TILE; ++jq) {
         __syncthreads();
-        load_tile(base + (long)jq * TILE * rs, rs, Qs, tid);
-        load_tile(dobase + (long)jq * TILE * ors, ors, Os, tid);
+        stash_tile(Qs, tid, pq);
+        stash_tile(Os, tid, po);
         if (tid < TILE) { lse_s[tid] = lse_b[jq * TILE + tid] * 1.4426950408889634f; del_s[tid] = del_b[jq * TILE + tid]; }
         __syncthreads();
+        if (jq + 1 < T / TILE) {
+            fetch_tile(base + (long)(jq + 1) * TILE * rs, rs, tid, pq);
+            fetch_tile(dobase + (long)(jq + 1) * TILE * ors, ors, tid, po);
+        }
         if (jq * TILE + TILE - 1 < kw0) continue;                 // wave-uniform: all queries are before the wave's keys
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
@@ -294,11 +321,18 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const unsigned short* _
     zero16(dQt[0]); zero16(dQt[1]);
 
     const int ntiles = (q0 + 128) / TILE;
+    u32x4 pk[2], pv[2];
+    fetch_tile(kbase, rs, tid, pk);
+    fetch_tile(vbase, rs, tid, pv);
     for (int j = 0; j < ntiles; ++j) {
         __syncthreads();
-        load_tile(kbase + (long)j * TILE * rs, rs, Ks, tid);
-        load_tile(vbase + (long)j * TILE * rs, rs, Vs, tid);
+        stash_tile(Ks, tid, pk);
+        stash_tile(Vs, tid, pv);
         __syncthreads();
+        if (j + 1 < ntiles) {
+            fetch_tile(kbase + (long)(j + 1) * TILE * rs, rs, tid, pk);
+            fetch_tile(vbase + (long)(j + 1) * TILE * rs, rs, tid, pv);
+        }
         if (j * TILE > qw0 + 31) continue;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {

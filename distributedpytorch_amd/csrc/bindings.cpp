@@ -74,6 +74,110 @@ std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::opti
     return {y};
 }
 
+// ---- recompute-instead-of-store: a 1x1 conv in front of a BatchNorm, with the BatchNorm fused into the
+//      conv epilogue (csrc/kernels.h, ConvArgs::epi).  The raw conv output is never written. ----
+static dpa::ConvArgs fused_args(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad, const char* who) {
+    CHECK_BF16(x); CHECK_BF16(w);
+    TORCH_CHECK(x.dim() == 4 && w.dim() == 4 && w.size(3) == x.size(3), who, ": NHWC x / KRSC w expected");
+    const int64_t N = x.size(0), H = x.size(1), W = x.size(2), C = x.size(3);
+    const int64_t K = w.size(0), R = w.size(1), S = w.size(2);
+    const int64_t Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    TORCH_CHECK(C % 8 == 0 && K % 8 == 0 && Ho > 0 && Wo > 0, who, ": bad geometry");
+    TORCH_CHECK(x.numel() < (1ll << 30) && w.numel() < (1ll << 30) && N * Ho * Wo < (1ll << 31), who, ": operands too large");
+    dpa::ConvArgs a{};
+    a.x = x.data_ptr(); a.w = w.data_ptr();
+    a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.Ho = Ho; a.Wo = Wo;
+    a.stride = stride; a.pad = pad; a.mode = 0; a.act = 0;
+    return a;
+}
+static void check_stats_buf(const Tensor& sb, int64_t K) {
+    CHECK_F32(sb);
+    TORCH_CHECK(sb.dim() == 3 && sb.size(1) == 2 && sb.size(2) == K && sb.size(0) >= 1, "stats buffer must be [rows,2,K]");
+}
+static void check_like_output(const Tensor& t, const dpa::ConvArgs& a, const char* what) {
+    CHECK_BF16(t);
+    TORCH_CHECK(t.numel() == (int64_t)a.N * a.Ho * a.Wo * a.K, what, " must have the conv output's shape");
+}
+static const uint8_t* check_mask(const Tensor& m, const dpa::ConvArgs& a) {
+    TORCH_CHECK(m.is_cuda() && m.scalar_type() == at::kByte && m.is_contiguous() &&
+                m.numel() * 8 == (int64_t)a.N * a.Ho * a.Wo * a.K, "mask must be uint8 with one bit per output element");
+    return m.data_ptr<uint8_t>();
+}
+
+// statistics-only pass: (sum, sumsq) of conv(x, w) per channel are ADDED into stats_buf; nothing else is written
+void conv_fprop_stats(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad, Tensor& stats_buf) {
+    dpa::ConvArgs a = fused_args(x, w, stride, pad, "conv_fprop_stats");
+    check_stats_buf(stats_buf, a.K);
+    Guard g(x);
+    a.y = nullptr; a.stats = stats_buf.data_ptr<float>(); a.stats_rows = stats_buf.size(0);
+    dpa::conv_igemm(a, cur_stream());
+}
+
+// out = relu(conv(x, w) * scale + shift + residual), plus its 1-bit mask
+std::vector<Tensor> conv_bn_res_relu(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad, const Tensor& scale,
+                                     const Tensor& shift, const Tensor& residual) {
+    dpa::ConvArgs a = fused_args(x, w, stride, pad, "conv_bn_res_relu");
+    CHECK_F32(scale); CHECK_F32(shift);
+    TORCH_CHECK(scale.numel() == a.K && shift.numel() == a.K, "conv_bn_res_relu: scale/shift size");
+    check_like_output(residual, a, "residual");
+    Guard g(x);
+    Tensor y = torch::empty({a.N, a.Ho, a.Wo, a.K}, x.options());
+    Tensor mask = torch::empty({y.numel() / 8}, x.options().dtype(at::kByte));
+    a.y = y.data_ptr(); a.epi = 1; a.ep_a = scale.data_ptr<float>(); a.ep_b = shift.data_ptr<float>();
+    a.ep_src = residual.data_ptr(); a.ep_mask_out = mask.data_ptr<uint8_t>();
+    dpa::conv_igemm(a, cur_stream());
+    return {y, mask};
+}
+
+// BN backward, reduction pass on the recomputed conv output: adds (sum g, sum g*c) into stats_buf, g = dout under mask
+void conv_bnb_stats(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad, const Tensor& dout, const Tensor& mask,
+                    Tensor& stats_buf) {
+    dpa::ConvArgs a = fused_args(x, w, stride, pad, "conv_bnb_stats");
+    check_like_output(dout, a, "dout");
+    check_stats_buf(stats_buf, a.K);
+    Guard g(x);
+    a.y = nullptr; a.epi = 2; a.ep_src = dout.data_ptr(); a.ep_mask_in = check_mask(mask, a);
+    a.ep_stats = stats_buf.data_ptr<float>(); a.ep_stats_rows = stats_buf.size(0);
+    dpa::conv_igemm(a, cur_stream());
+}
+
+// BN backward, apply pass: d(conv out) = cA * g + cB * c + cC with c recomputed
+Tensor conv_bnb_apply(const Tensor& x, const Tensor& w, int64_t stride, int64_t pad, const Tensor& dout, const Tensor& mask,
+                      const Tensor& cA, const Tensor& cB, const Tensor& cC) {
+    dpa::ConvArgs a = fused_args(x, w, stride, pad, "conv_bnb_apply");
+    check_like_output(dout, a, "dout");
+    CHECK_F32(cA); CHECK_F32(cB); CHECK_F32(cC);
+    TORCH_CHECK(cA.numel() == a.K && cB.numel() == a.K && cC.numel() == a.K, "conv_bnb_apply: coefficient sizes");
+    Guard g(x);
+    Tensor y = torch::empty({a.N, a.Ho, a.Wo, a.K}, x.options());
+    a.y = y.data_ptr(); a.epi = 3; a.ep_a = cA.data_ptr<float>(); a.ep_b = cB.data_ptr<float>(); a.ep_c = cC.data_ptr<float>();
+    a.ep_src = dout.data_ptr(); a.ep_mask_in = check_mask(mask, a);
+    dpa::conv_igemm(a, cur_stream());
+    return y;
+}
+
+// (sum g, sum g*x) accumulated by conv_bnb_stats -> dgamma, dbeta (accumulated into the targets when given) and
+// the apply-pass coefficients; re-zeroes stats_buf.  Returns [5, C]: dgamma, dbeta, cA, cB, cC.
+Tensor bn_bwd_coefs(Tensor& stats_buf, int64_t P, const Tensor& gamma, const Tensor& mean, const Tensor& invstd,
+                    const c10::optional<Tensor>& dgamma_acc, const c10::optional<Tensor>& dbeta_acc) {
+    CHECK_F32(gamma); CHECK_F32(mean); CHECK_F32(invstd);
+    const int64_t C = gamma.numel();
+    check_stats_buf(stats_buf, C);
+    TORCH_CHECK(mean.numel() == C && invstd.numel() == C, "bn_bwd_coefs: sizes");
+    Guard g(gamma);
+    Tensor co = torch::empty({5, C}, gamma.options());
+    float* o = co.data_ptr<float>();
+    float* dg = o; float* db = o + C; int accumulate = 0;
+    if (dgamma_acc.has_value() && dgamma_acc->defined()) {
+        CHECK_F32((*dgamma_acc)); CHECK_F32((*dbeta_acc));
+        TORCH_CHECK(dgamma_acc->numel() == C && dbeta_acc->numel() == C, "bn_bwd_coefs: accumulate targets");
+        dg = dgamma_acc->data_ptr<float>(); db = dbeta_acc->data_ptr<float>(); accumulate = 1;
+    }
+    dpa::bn_bwd_finalize(stats_buf.data_ptr<float>(), stats_buf.size(0), P, C, gamma.data_ptr<float>(), mean.data_ptr<float>(),
+                         invstd.data_ptr<float>(), dg, db, accumulate, o + 2 * C, o + 3 * C, o + 4 * C, 1, 1, cur_stream());
+    return co;
+}
+
 // dgrad: dy [N,Ho,Wo,K] bf16, wt [C,R,S,K] bf16 (filter with K and C swapped) -> dx [N,H,W,C]
 Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int64_t stride, int64_t pad,
                   const c10::optional<Tensor>& addend, const c10::optional<Tensor>& addend_mask) {
@@ -255,7 +359,7 @@ std::vector<Tensor> bn_backward(const Tensor& dy, const c10::optional<Tensor>& m
         dg = dgamma_acc->data_ptr<float>(); db = dbeta_acc->data_ptr<float>(); accumulate = 1;
     }
     dpa::bn_bwd_finalize(stats.data_ptr<float>(), rows, P, C, gamma.data_ptr<float>(), mean.data_ptr<float>(),
-                         invstd.data_ptr<float>(), dg, db, accumulate, o + 2 * C, o + 3 * C, o + 4 * C, reset, cur_stream());
+                         invstd.data_ptr<float>(), dg, db, accumulate, o + 2 * C, o + 3 * C, o + 4 * C, reset, 0, cur_stream());
     Tensor dx = torch::empty_like(x);
     dpa::bn_bwd_apply(dy.data_ptr(), mk, x.data_ptr(), o + 2 * C, o + 3 * C, o + 4 * C, dx.data_ptr(), P, C, relu, cur_stream());
     return {dx, co[0], co[1]};
@@ -547,6 +651,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "distributedpytorch_amd gfx950 kernels";
     m.def("conv_fprop", &conv_fprop);
     m.def("conv_dgrad", &conv_dgrad);
+    m.def("conv_fprop_stats", &conv_fprop_stats);
+    m.def("conv_bn_res_relu", &conv_bn_res_relu);
+    m.def("conv_bnb_stats", &conv_bnb_stats);
+    m.def("conv_bnb_apply", &conv_bnb_apply);
+    m.def("bn_bwd_coefs", &bn_bwd_coefs);
     m.def("conv_wgrad", &conv_wgrad);
     m.def("transpose_filter", &transpose_filter);
     m.def("colsum", &colsum);

@@ -333,11 +333,88 @@ __global__ __launch_bounds__(256, RING ? ((WP == 4 && !ONE) ? 2 : 3) : 4) void c
     constexpr int CPR = BC / 8;        // chunks per row
     constexpr int RPP = 256 / CPR;     // rows per pass
     const int och = tid % CPR, orow = tid / CPR;
+    const int co = c0 + och * 8;       // this thread's 8 channels are the same in every pass
+
+    // Fused BatchNorm epilogues (a.epi != 0; MODE 0 only).  They let a cheap 1x1 conv in front of a
+    // BatchNorm be RECOMPUTED instead of stored: the raw conv output never goes to memory.
+    //   epi 1: y = relu(c * ep_a[ch] + ep_b[ch] + ep_src) and its 1-bit mask      (BN apply + residual + ReLU)
+    //   epi 2: no output; adds sum(g), sum(g * c) per channel into ep_stats        (BN backward, reduction pass)
+    //   epi 3: y = ep_a[ch] * g + ep_b[ch] * c + ep_c[ch]                          (BN backward, apply pass)
+    // with c = the bf16-rounded conv output of this tile, g = ep_src under the bit mask ep_mask_in.
+    if (MODE == 0 && a.epi != 0) {
+        const unsigned short* srcg = (const unsigned short*)a.ep_src;
+        float ea[8], eb[8], ec[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ch = min(co + j, a.K - 1);
+            ea[j] = a.epi != 2 ? a.ep_a[ch] : 0.f;
+            eb[j] = a.epi != 2 ? a.ep_b[ch] : 0.f;
+            ec[j] = a.epi == 3 ? a.ep_c[ch] : 0.f;
+        }
+        float s8[8], q8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s8[j] = 0.f; q8[j] = 0.f; }
+#pragma unroll
+        for (int pss = 0; pss < BP / RPP; ++pss) {
+            const int row = pss * RPP + orow;
+            const long m = m0 + row;
+            if (m < M && co < a.K) {
+                const long e0 = m * a.K + co;
+                float c[8], g[8];
+                { const uint4 v = *(const uint4*)(cs + row * CS + och * 8); unpack8(v, c); }
+                { const uint4 v = *(const uint4*)(srcg + e0); unpack8(v, g); }
+                if (a.epi == 1) {
+                    unsigned mk = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float t = fmaxf(c[j] * ea[j] + eb[j] + g[j], 0.f);
+                        c[j] = t;
+                        mk |= (t > 0.f ? 1u : 0u) << j;
+                    }
+                    *(uint4*)(yg + e0) = pack8(c);
+                    a.ep_mask_out[e0 >> 3] = (unsigned char)mk;
+                } else {
+                    const unsigned mk = a.ep_mask_in[e0 >> 3];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] = ((mk >> j) & 1u) ? g[j] : 0.f;
+                    if (a.epi == 2) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { s8[j] += g[j]; q8[j] += g[j] * c[j]; }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) c[j] = ea[j] * g[j] + eb[j] * c[j] + ec[j];
+                        *(uint4*)(yg + e0) = pack8(c);
+                    }
+                }
+            }
+        }
+        if (a.epi == 2) {
+            // fold the RPP row groups through LDS (the staged tile is dead once everyone has read it)
+            __syncthreads();
+            float* red = (float*)smem;                       // [2][RPP][BC]
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                red[(0 * RPP + orow) * BC + och * 8 + j] = s8[j];
+                red[(1 * RPP + orow) * BC + och * 8 + j] = q8[j];
+            }
+            __syncthreads();
+            for (int o = tid; o < 2 * BC; o += 256) {
+                const int st_ = o / BC, ch = o - st_ * BC;
+                float t = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < RPP; ++r) t += red[(st_ * RPP + r) * BC + ch];
+                if (c0 + ch < a.K)
+                    atomicAdd(a.ep_stats + ((long)(tile_p % a.ep_stats_rows) * 2 + st_) * a.K + c0 + ch, t);
+            }
+        }
+        return;
+    }
+    if (yg == nullptr) return;          // statistics-only pass
+
 #pragma unroll
     for (int pss = 0; pss < BP / RPP; ++pss) {
         const int row = pss * RPP + orow;
         const long m = m0 + row;
-        const int co = c0 + och * 8;
         if (m < M && co < a.K) {
             long orow_g = m;           // output pixel index in [N][Ho][Wo]
             if (MODE == 2) {

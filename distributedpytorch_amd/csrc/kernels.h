@@ -29,6 +29,18 @@ struct ConvArgs {
     int stride, pad;
     int mode;           // 0 fprop, 1 dgrad
     int act;            // 0 none, 1 relu, 2 gelu(tanh)
+    // Fused BatchNorm epilogues (fprop only), c = this conv's bf16-rounded output, never written when epi != 0:
+    //   epi 1: y = relu(c * ep_a[k] + ep_b[k] + ep_src), mask bits -> ep_mask_out
+    //   epi 2: no y; g = ep_src under ep_mask_in; (sum g, sum g*c) per channel are ADDED into ep_stats
+    //          ([ep_stats_rows][2][K] fp32, zero before the launch)
+    //   epi 3: y = ep_a[k] * g + ep_b[k] * c + ep_c[k]
+    // y == nullptr with epi == 0: statistics-only pass (only `stats` is produced).
+    int epi;
+    const float* ep_a; const float* ep_b; const float* ep_c;
+    const void* ep_src;                 // bf16 [N, Ho, Wo, K]
+    const unsigned char* ep_mask_in;
+    unsigned char* ep_mask_out;
+    float* ep_stats; int ep_stats_rows;
 };
 void conv_igemm(const ConvArgs& a, hipStream_t st);
 int conv_stats_rows(long M);  // replica rows of the stats buffer
@@ -70,9 +82,10 @@ void bn_apply(const void* x, const void* residual, void* y, const float* scale, 
 void bn_bwd_stats(const void* dy, const unsigned char* mask, const void* x, const float* mean, const float* invstd,
                   float* stats, long P, int C, int relu, int replicas, hipStream_t st);
 // reduce partials -> dgamma, dbeta (accumulate=0: overwrite) and coefficients A,B,C0 with dx = A*g + B*x + C0
+// raw_x: the second statistic is sum(g * x) (raw conv output) instead of sum(g * xhat); converted here
 void bn_bwd_finalize(float* stats, int rows, long P, int C, const float* gamma, const float* mean,
                      const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coefA, float* coefB,
-                     float* coefC, int reset_stats, hipStream_t st);
+                     float* coefC, int reset_stats, int raw_x, hipStream_t st);
 // backward pass 2: dx = A*g + B*x + C0
 void bn_bwd_apply(const void* dy, const unsigned char* mask, const void* x, const float* coefA, const float* coefB,
                   const float* coefC, void* dx, long P, int C, int relu, hipStream_t st);

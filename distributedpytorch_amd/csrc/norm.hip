@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
                                                               const float* __restrict__ invstd, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate,
                                                               float* __restrict__ cA, float* __restrict__ cB,
-                                                              float* __restrict__ cC, int reset) {
+                                                              float* __restrict__ cC, int reset, int raw_x) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     __shared__ double red[2][4][64];
     double s = 0.0, q = 0.0;
@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
         const int l = threadIdx.x & 63;
         s = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];   // sum g       = dbeta
         q = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];   // sum g*xhat  = dgamma
+        if (raw_x) q = (double)invstd[c] * (q - (double)mean[c] * s);    // came in as sum g*x
         if (accumulate) { dbeta[c] += (float)s; dgamma[c] += (float)q; }
         else { dbeta[c] = (float)s; dgamma[c] = (float)q; }
         const double g = gamma[c], is = invstd[c], m = mean[c], invP = 1.0 / (double)P;
@@ -288,9 +289,9 @@ void bn_bwd_stats(const void* dy, const unsigned char* mask, const void* x, cons
 
 void bn_bwd_finalize(float* stats, int rows, long P, int C, const float* gamma, const float* mean,
                      const float* invstd, float* dgamma, float* dbeta, int accumulate, float* coefA, float* coefB,
-                     float* coefC, int reset_stats, hipStream_t st) {
+                     float* coefC, int reset_stats, int raw_x, hipStream_t st) {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, stats, rows, P, C, gamma, mean, invstd,
-                       dgamma, dbeta, accumulate, coefA, coefB, coefC, reset_stats);
+                       dgamma, dbeta, accumulate, coefA, coefB, coefC, reset_stats, raw_x);
 }
 
 void bn_bwd_apply(const void* dy, const unsigned char* mask, const void* x, const float* coefA, const float* coefB,

@@ -22,6 +22,15 @@ from . import _ext
 from . import sink as _sink
 
 ENABLED = os.environ.get("DPA_NO_FUSED_BLOCK", "0") != "1"
+# Optional: conv3 + bn3 RECOMPUTED instead of stored when conv3's output is at least DPA_RECOMPUTE_MB big.
+# The 1x1 conv is cheap on the matrix cores and its output is the largest tensor of the block, so forward can
+# run it twice (statistics pass, then BN + residual + ReLU in the conv epilogue) and backward twice more
+# (reduction pass, apply pass) without ever writing the raw conv output: -3.25 tensor passes and -1 stored
+# tensor per block.  Measured on MI355X, batch 256 (scripts/bench_recompute.py): layer-1 forward 394 -> 323 us,
+# but backward 422 -> 508 us - the conv kernel's epilogue streams at ~3 TB/s where the dedicated BatchNorm
+# kernels reach ~5 TB/s - so it is a MEMORY-saving option (off by default), not a speed-up, until the epilogue
+# is as good a streamer as norm.hip.
+RECOMPUTE_MIN_BYTES = int(float(os.environ.get("DPA_RECOMPUTE_MB", "1e12")) * 2 ** 20)
 
 
 def _conv_bn_fwd(C, conv, bn, x, relu, residual=None):
@@ -68,7 +77,20 @@ class _BottleneckFn(torch.autograd.Function):
             idn = x
         c1, a1, m1, i1, k1 = _conv_bn_fwd(C, blk.conv1, blk.bn1, x, True)
         c2, a2, m2, i2, k2 = _conv_bn_fwd(C, blk.conv2, blk.bn2, a1, True)
-        c3, out, m3, i3, k3 = _conv_bn_fwd(C, blk.conv3, blk.bn3, a2, True, idn)
+        conv3, bn3 = blk.conv3, blk.bn3
+        out_bytes = a2.numel() // a2.shape[-1] * conv3.weight_lp.shape[0] * 2
+        recompute = out_bytes >= RECOMPUTE_MIN_BYTES and conv3.stride == 1 and conv3.padding == 0
+        if recompute:
+            sb = bn3.stats_buffer(x.device)
+            C.conv_fprop_stats(a2, conv3.weight_lp, 1, 0, sb)
+            P = a2.numel() // a2.shape[-1]
+            m3, i3, scale, shift = C.bn_finalize(sb, P, bn3.weight.detach(), bn3.bias.detach(), bn3.running_mean,
+                                                 bn3.running_var, bn3.momentum, bn3.eps, True)
+            out, k3 = C.conv_bn_res_relu(a2, conv3.weight_lp, 1, 0, scale, shift, idn)
+            c3 = a2.new_empty(0)                       # placeholder: the raw conv output does not exist
+        else:
+            c3, out, m3, i3, k3 = _conv_bn_fwd(C, conv3, bn3, a2, True, idn)
+        ctx.recompute = recompute
         # the ReLU masks travel as 1 bit per element: the backward pass never re-reads an activation for its sign
         saved = [x, c1, a1, m1, i1, k1, c2, a2, m2, i2, k2, c3, m3, i3, k3]
         if ds:
@@ -89,7 +111,21 @@ class _BottleneckFn(torch.autograd.Function):
         grads = [None] * n_params          # order: conv1.w bn1.w bn1.b conv2.w bn2.w bn2.b conv3.w bn3.w bn3.b [ds.w dsbn.w dsbn.b]
         # bn3 behind the residual join: the masked dout is both bn3's incoming gradient and the gradient of the
         # shortcut branch; it is never materialised (consumers apply the bit mask k3 themselves)
-        d3 = _bn_bwd(C, blk.bn3, dout, k3, c3, m3, i3, True, grads, 7)
+        if ctx.recompute:
+            bn3, w3 = blk.bn3, blk.conv3.weight_lp
+            sb = bn3.stats_buffer_bwd(dout.device)
+            C.conv_bnb_stats(a2, w3, 1, 0, dout, k3, sb)
+            tg, tb = _sink.target(bn3.weight), _sink.target(bn3.bias)
+            sunk = tg is not None and tb is not None
+            co = C.bn_bwd_coefs(sb, dout.numel() // dout.shape[-1], bn3.weight.detach(), m3, i3,
+                                tg if sunk else None, tb if sunk else None)
+            if sunk:
+                _sink.ready(bn3.weight); _sink.ready(bn3.bias)
+            else:
+                grads[7], grads[8] = co[0], co[1]
+            d3 = C.conv_bnb_apply(a2, w3, 1, 0, dout, k3, co[2], co[3], co[4])
+        else:
+            d3 = _bn_bwd(C, blk.bn3, dout, k3, c3, m3, i3, True, grads, 7)
         _wgrad(C, blk.conv3, a2, d3, grads, 6)
         da2 = C.conv_dgrad(d3, C.transpose_filter(blk.conv3.weight_lp), a2.shape[1], a2.shape[2], 1, 0, None, None)
         d2 = _bn_bwd(C, blk.bn2, da2, k2, c2, m2, i2, True, grads, 4)

@@ -50,7 +50,7 @@ def test_fused_block_matches_op_by_op_path():
     from distributedpytorch_amd.parallel.flat import FlatParams
     x = torch.randn(8, 3, 64, 64, device=DEV); y = torch.randint(0, 16, (8,), device=DEV)
     grads = []
-    for enabled in (True, False):
+    for enabled in (True, False, "recompute"):
         torch.manual_seed(1)
         m = resnet.tiny_resnet().to(DEV).train()
         for mod in m.modules():      # non-trivial BN affine (bn3 gamma is zero-initialised)
@@ -58,16 +58,23 @@ def test_fused_block_matches_op_by_op_path():
                 torch.nn.init.uniform_(mod.weight, 0.5, 1.5); torch.nn.init.normal_(mod.bias, 0.0, 0.2)
         flat = FlatParams(m)
         flat.install_sink(None)
-        block.ENABLED = enabled
+        block.ENABLED = bool(enabled)
+        keep = block.RECOMPUTE_MIN_BYTES
+        block.RECOMPUTE_MIN_BYTES = 0 if enabled == "recompute" else 1 << 60   # force / forbid conv3+bn3 recomputation
         try:
             loss = m.loss(x, y)
             loss.backward()
         finally:
             block.ENABLED = True
+            block.RECOMPUTE_MIN_BYTES = keep
             from distributedpytorch_amd.ops import sink
             sink.uninstall()
         grads.append((float(loss.detach()), flat.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters()}))
-    (l1, g1, d1), (l2, g2, d2) = grads
+    for (l1, g1, d1), (l2, g2, d2) in ((grads[0], grads[1]), (grads[2], grads[1])):
+        _compare_paths(l1, g1, d1, l2, g2, d2)
+
+
+def _compare_paths(l1, g1, d1, l2, g2, d2):
     assert abs(l1 - l2) < 1e-3
     # The BN statistics are summed with fp32 atomics (order varies run to run), so an activation
     # within one bf16 rounding of zero can land on either side of a ReLU mask: single elements of
