@@ -112,7 +112,7 @@ def build(verbose: bool = True, jobs: int = 8) -> Path:
             print(f"[build_ext] linking {out.name}", flush=True)
         _run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", *map(str, objs), "-o", str(out),
               f"-L{lib_dir}", "-lc10", "-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10_hip", "-ltorch_hip",
-              "-lamdhip64"])
+              "-lamdhip64", "-lrccl", f"-Wl,-rpath,{lib_dir}"])   # the RCCL torch itself loads (one RCCL per process)
         stamp.write_text(key)
         # drop objects of older source versions
         keep = {o.name for o in objs}

@@ -47,11 +47,11 @@ def resolve_backend(backend: str, device: Optional[torch.device] = None) -> str:
 def rccl_env_defaults() -> None:
     """Environment for RCCL over the 8-GPU xGMI mesh.  Only sets defaults.
 
-    Each MI355X has 7 point-to-point xGMI links (one per peer); more channels let
-    RCCL drive several links at once instead of a single ring pair.
+    RCCL's own channel / algorithm tuning for gfx950 is left alone: nothing here could be measured on
+    more than one GPU, and an unmeasured override (e.g. NCCL_MIN_NCHANNELS) takes CUs from the
+    overlapped backward kernels.
     """
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ.setdefault("NCCL_MIN_NCHANNELS", "32")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (required by the host driver)
     os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
 
 
@@ -85,7 +85,10 @@ def init_process_group(backend: str = "auto", init_method: Optional[str] = None,
         kwargs["device_id"] = device
     if not dist.is_initialized():
         dist.init_process_group(**kwargs)
-    return Communicator(group=None, device=device)
+    comm = Communicator(group=None, device=device)
+    if os.environ.get("DPA_COMM", "c10d").lower() == "native" and be == "nccl" and device is not None and device.type == "cuda":
+        comm.attach_native()
+    return comm
 
 
 def destroy_process_group() -> None:
@@ -99,6 +102,21 @@ def get_rank() -> int:
 
 def get_world_size() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
+
+
+class _NativeWork:
+    """Handle of an operation on the native RCCL communicator's stream (csrc/rccl_comm.cpp)."""
+
+    def __init__(self, native, ticket: int, keep=()):
+        self._native, self._ticket, self._keep = native, ticket, keep
+
+    def wait(self):
+        self._native.wait(self._ticket)      # the current compute stream waits on the event; no host block
+        self._keep = ()
+        return True
+
+    def is_completed(self):
+        return False
 
 
 class _DoneWork:
@@ -122,6 +140,36 @@ class Communicator:
         self.device = device
         self._ranks = list(ranks) if ranks is not None else None
         self.initialized = dist.is_initialized()
+        self.native = None                    # optional csrc/rccl_comm.cpp communicator over the same ranks
+        self._direct = os.environ.get("DPA_ALLREDUCE", "ring").lower() == "direct"
+        self._scratch = {}
+
+    # ---- native RCCL communicator (DPA_COMM=native): own comm stream, hipEvent hand-offs, direct all-reduce ----
+    def attach_native(self) -> None:
+        """Collective over this communicator's ranks: bootstrap a native ``RcclComm`` (the 128-byte unique id
+        travels through the existing process group) and route device all-reduces through it."""
+        from .ops import _ext
+        C = _ext.load()
+        if self.device is None or self.device.type != "cuda":
+            raise RuntimeError("the native RCCL communicator needs a GPU device")
+        box = [C.RcclComm.unique_id() if self.rank == 0 else None]
+        if self.world_size > 1:
+            dist.broadcast_object_list(box, src=self.to_global(0), group=self.group)
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.native = C.RcclComm(box[0], self.rank, self.world_size, index)
+
+    def _native_all_reduce(self, tensor: torch.Tensor, op):
+        code = {dist.ReduceOp.SUM: 0, dist.ReduceOp.MAX: 1, dist.ReduceOp.MIN: 2}.get(op)
+        if code is None or not tensor.is_cuda or not tensor.is_contiguous():
+            return None
+        if self._direct and code == 0 and tensor.dtype == torch.float32 and self.world_size > 1:
+            shard = -(-tensor.numel() // self.world_size)
+            need = shard * (self.world_size - 1)
+            scratch = self._scratch.get(need)
+            if scratch is None:
+                scratch = self._scratch[need] = torch.empty(need, dtype=torch.float32, device=tensor.device)
+            return _NativeWork(self.native, self.native.all_reduce_direct(tensor, scratch), (tensor,))
+        return _NativeWork(self.native, self.native.all_reduce(tensor, code), (tensor,))
 
     # ---- queries (reference: dist.get_rank / get_world_size, DP.py:108,112) ----
     @property
@@ -147,6 +195,15 @@ class Communicator:
 
     # ---- collectives ----
     def all_reduce(self, tensor: torch.Tensor, op=dist.ReduceOp.SUM, async_op: bool = False):
+        if self.native is not None:
+            work = self._native_all_reduce(tensor, op)
+            if work is not None:
+                if _SYNC_DEBUG:
+                    self.native.synchronize()
+                if async_op:
+                    return work
+                work.wait()
+                return None
         if self.world_size == 1:
             return _DoneWork() if async_op else None
         work = dist.all_reduce(tensor, op=op, group=self.group, async_op=True)
@@ -259,7 +316,10 @@ class Communicator:
         ranks = list(ranks)
         group = dist.new_group(ranks=ranks)
         if dist.get_rank() in ranks:
-            return Communicator(group=group, device=self.device, ranks=ranks)
+            sub = Communicator(group=group, device=self.device, ranks=ranks)
+            if self.native is not None:
+                sub.attach_native()
+            return sub
         return None
 
 

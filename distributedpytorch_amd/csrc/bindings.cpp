@@ -646,6 +646,7 @@ Tensor mul_f32(const Tensor& a, const Tensor& b) {
 }  // namespace
 
 void bind_transformer(pybind11::module_& m);  // bindings_tfm.cpp
+void bind_rccl(pybind11::module_& m);         // rccl_comm.cpp
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "distributedpytorch_amd gfx950 kernels";
@@ -686,6 +687,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("nll_bwd", &nll_bwd);
     m.def("dropout_mask", &dropout_mask);
     m.def("counter_add", &counter_add);
+    m.def("reduce_shards", [](Tensor& dst, const Tensor& src, int64_t nsrc, int64_t stride) {
+        CHECK_F32(dst); CHECK_F32(src);
+        TORCH_CHECK(src.numel() >= (nsrc - 1) * stride + dst.numel(), "reduce_shards: src too small");
+        Guard g(dst);
+        dpa::reduce_shards(dst.data_ptr<float>(), src.data_ptr<float>(), (int)nsrc, stride, dst.numel(), cur_stream());
+    });
     m.def("mul_f32", &mul_f32);
     bind_transformer(m);
+    bind_rccl(m);
 }

@@ -372,6 +372,32 @@ void dropout_mask(float* mask, long n, float p, uint64_t seed, uint64_t offset, 
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, st, mask, n, p, seed, offset, step);
 }
 
+// dst[i] += sum_k src[k * stride + i]   (N-way fp32 reduction of the direct all-reduce, 16 B per lane)
+__global__ __launch_bounds__(256) void reduce_shards_kernel(float* __restrict__ dst, const float* __restrict__ src, int nsrc,
+                                                            long stride, long n) {
+    const long n4 = n / 4;
+    const bool vec = (stride % 4 == 0) && ((uintptr_t)dst % 16 == 0) && ((uintptr_t)src % 16 == 0);
+    if (vec) {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+            float4 a = ((const float4*)dst)[i];
+            for (int k = 0; k < nsrc; ++k) {
+                const float4 b = *(const float4*)(src + (long)k * stride + i * 4);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            ((float4*)dst)[i] = a;
+        }
+    }
+    for (long i = (vec ? n4 * 4 : 0) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float a = dst[i];
+        for (int k = 0; k < nsrc; ++k) a += src[(long)k * stride + i];
+        dst[i] = a;
+    }
+}
+
+void reduce_shards(float* dst, const float* src, int nsrc, long stride, long n, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_shards_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, dst, src, nsrc, stride, n);
+}
+
 __global__ void counter_add_kernel(int64_t* c, int64_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += v; }
 
 void counter_add(int64_t* c, int64_t v, hipStream_t st) { hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, st, c, v); }

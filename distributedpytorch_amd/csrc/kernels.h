@@ -157,7 +157,9 @@ void log_softmax_bwd(const float* dy, const float* y, float* dx, int rows, int V
 void nll_fwd(const float* logp, const int64_t* t, float* loss, int rows, int V, hipStream_t st);
 void nll_bwd(const float* g, const int64_t* t, float* dlogp, int rows, int V, hipStream_t st);
 void dropout_mask(float* mask, long n, float p, uint64_t seed, uint64_t offset, const int64_t* step, hipStream_t st);
-void counter_add(int64_t* c, int64_t v, hipStream_t st);   // device-resident step counter (graph-replay safe)
+void counter_add(int64_t* c, int64_t v, hipStream_t st);
+// dst[i] += sum_{k<nsrc} src[k*stride + i], i < n (fp32; local step of the direct all-reduce)
+void reduce_shards(float* dst, const float* src, int nsrc, long stride, long n, hipStream_t st);   // device-resident step counter (graph-replay safe)
 void mul_f32(const float* a, const float* b, float* y, long n, hipStream_t st);
 
 }  // namespace dpa

@@ -153,3 +153,32 @@ def test_mnist_hipgraph_step_matches_eager_and_draws_fresh_masks():
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
     assert not torch.equal(grads_graph[0], grads_graph[1])     # fresh dropout masks per replay
     assert int(m2._drop.dev_step.item()) == 2
+
+
+def test_native_rccl_communicator_single_rank():
+    """csrc/rccl_comm.cpp at world size 1 (all a one-GPU box allows): bootstrap, comm-stream ordering against
+    the compute stream, ring and direct all-reduce, broadcast, reduce-scatter / all-gather, ticket waits."""
+    from distributedpytorch_amd.ops import _ext
+    C = _ext.load()
+    nc = C.RcclComm(C.RcclComm.unique_id(), 0, 1, torch.cuda.current_device())
+    assert nc.rank == 0 and nc.world_size == 1
+    x = torch.randn(1 << 20, device=DEV)
+    ref = x.clone()
+    y = x * 2.0                                   # producer on the compute stream; the comm stream must wait for it
+    t = nc.all_reduce(y, 0)
+    nc.wait(t)
+    z = y + 1.0                                   # consumer on the compute stream, ordered behind the ticket
+    torch.testing.assert_close(z, ref * 2.0 + 1.0)
+    scratch = torch.empty(0, device=DEV)
+    nc.wait(nc.all_reduce_direct(y, scratch))
+    torch.testing.assert_close(y, ref * 2.0)
+    nc.wait(nc.broadcast(y, 0))
+    out = torch.empty_like(y)
+    nc.wait(nc.reduce_scatter(out, y)); torch.testing.assert_close(out, y)
+    out.zero_(); nc.wait(nc.all_gather(out, y)); torch.testing.assert_close(out, y)
+    nc.synchronize()
+    # the N-way reduction kernel of the direct algorithm: dst += sum of (world - 1) incoming shards
+    dst = torch.randn(1003, device=DEV); src = torch.randn(3, 1024, device=DEV)
+    want = dst + src[:, :1003].sum(0)
+    C.reduce_shards(dst, src.view(-1), 3, 1024)
+    torch.testing.assert_close(dst, want)
