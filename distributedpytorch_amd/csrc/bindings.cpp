@@ -239,6 +239,14 @@ Tensor transpose_filter(const Tensor& w) {
     return wt;
 }
 
+void transpose_filters_batched(const Tensor& src, Tensor& dst, const Tensor& table, int64_t total_tiles) {
+    CHECK_BF16(src); CHECK_BF16(dst); CHECK_I64(table);
+    TORCH_CHECK(table.dim() == 2 && table.size(1) == 6 && dst.numel() == src.numel() && total_tiles > 0, "transpose_filters_batched: shapes");
+    Guard g(src);
+    dpa::transpose_filters_batched(src.data_ptr(), dst.data_ptr(), (const long*)table.data_ptr<int64_t>(), (int)table.size(0),
+                                   total_tiles, cur_stream());
+}
+
 void colsum(const Tensor& x, Tensor& out) {
     CHECK_BF16(x); CHECK_F32(out);
     const int64_t K = x.size(-1);
@@ -659,6 +667,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("bn_bwd_coefs", &bn_bwd_coefs);
     m.def("conv_wgrad", &conv_wgrad);
     m.def("transpose_filter", &transpose_filter);
+    m.def("transpose_filters_batched", &transpose_filters_batched);
     m.def("colsum", &colsum);
     m.def("bn_stats", &bn_stats);
     m.def("bn_finalize", &bn_finalize);

@@ -54,6 +54,16 @@ __device__ __forceinline__ void reduce_rows(F f, float* __restrict__ stats, long
     }
 }
 
+// column sums of a [rows][2][C] statistics buffer for channel c over rows rl, rl+4, ...; optionally re-zeroes
+// what it read (each (row, channel) is read by exactly one thread)
+__device__ __forceinline__ void sum_and_reset(float* stats, int rows, int C, int c, int rl, int reset, double& s, double& q) {
+    for (int r = rl; r < rows; r += 4) {
+        float* ps = stats + ((long)r * 2) * C + c;
+        s += ps[0]; q += ps[C];
+        if (reset) { ps[0] = 0.f; ps[C] = 0.f; }
+    }
+}
+
 // C > 2048 (cpr > 256) is not used by BatchNorm layers here; wide C is tiled by grid.y
 __global__ __launch_bounds__(256) void bn_stats_kernel(const unsigned short* __restrict__ x, float* __restrict__ stats,
                                                        long P, int C, int rpb) {
@@ -74,12 +84,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(float* __restrict__ st
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     __shared__ double red[2][4][64];
     double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int r = rl; r < rows; r += 4) {
-            float* ps = stats + ((long)r * 2) * C + c;
-            s += ps[0]; q += ps[C];
-            if (reset) { ps[0] = 0.f; ps[C] = 0.f; }   // each (row, channel) is read by exactly one thread
-        }
+    if (c < C) sum_and_reset(stats, rows, C, c, rl, reset, s, q);
     red[0][rl][threadIdx.x & 63] = s; red[1][rl][threadIdx.x & 63] = q;
     __syncthreads();
     if (rl == 0 && c < C) {
@@ -89,7 +94,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(float* __restrict__ st
         const double m = s / (double)P;
         double var = q / (double)P - m * m;
         if (var < 0.0) var = 0.0;
-        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        // fp32 rsqrt + one Newton step (error < 1 ulp of fp32, which is what is stored): a double-precision
+        // sqrt and divide would be a quarter of this kernel's run time
+        const float vf = (float)(var + (double)eps);
+        float is = rsqrtf(vf);
+        is = is * (1.5f - 0.5f * vf * is * is);
         mean[c] = (float)m; invstd[c] = is;
         const float g = gamma[c];
         scale[c] = g * is;
@@ -164,12 +173,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     __shared__ double red[2][4][64];
     double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int r = rl; r < rows; r += 4) {
-            float* ps = stats + ((long)r * 2) * C + c;
-            s += ps[0]; q += ps[C];
-            if (reset) { ps[0] = 0.f; ps[C] = 0.f; }
-        }
+    if (c < C) sum_and_reset(stats, rows, C, c, rl, reset, s, q);
     red[0][rl][threadIdx.x & 63] = s; red[1][rl][threadIdx.x & 63] = q;
     __syncthreads();
     if (rl == 0 && c < C) {

@@ -33,6 +33,7 @@ class Conv2d(nn.Module):
         self.weight = nn.Parameter(w)
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
         self.weight_lp: Optional[torch.Tensor] = None
+        self.weight_lp_t: Optional[torch.Tensor] = None    # [C,R,S,K] twin for dgrad, kept by FlatParams
 
     def forward(self, x: torch.Tensor, want_stats: bool = False, stats_buf=None):
         y, stats = ops.conv2d_nhwc(x, self.weight, self.weight_lp, self.bias, self.stride, self.padding, want_stats,

@@ -54,6 +54,12 @@ def _bn_bwd(C, bn, dy, mask, x_raw, mean, invstd, relu, grads, slot):
     return dx
 
 
+def _wt(C, conv):
+    """Filter with K and C swapped for dgrad: the twin FlatParams keeps current, else transposed on the spot."""
+    wt = getattr(conv, "weight_lp_t", None)
+    return wt if wt is not None else C.transpose_filter(conv.weight_lp)
+
+
 def _wgrad(C, conv, x, dy, grads, slot):
     tgt = _sink.target(conv.weight)
     if tgt is not None:
@@ -127,10 +133,10 @@ class _BottleneckFn(torch.autograd.Function):
         else:
             d3 = _bn_bwd(C, blk.bn3, dout, k3, c3, m3, i3, True, grads, 7)
         _wgrad(C, blk.conv3, a2, d3, grads, 6)
-        da2 = C.conv_dgrad(d3, C.transpose_filter(blk.conv3.weight_lp), a2.shape[1], a2.shape[2], 1, 0, None, None)
+        da2 = C.conv_dgrad(d3, _wt(C, blk.conv3), a2.shape[1], a2.shape[2], 1, 0, None, None)
         d2 = _bn_bwd(C, blk.bn2, da2, k2, c2, m2, i2, True, grads, 4)
         _wgrad(C, blk.conv2, a1, d2, grads, 3)
-        da1 = C.conv_dgrad(d2, C.transpose_filter(blk.conv2.weight_lp), a1.shape[1], a1.shape[2],
+        da1 = C.conv_dgrad(d2, _wt(C, blk.conv2), a1.shape[1], a1.shape[2],
                            blk.conv2.stride, blk.conv2.padding, None, None)
         d1 = _bn_bwd(C, blk.bn1, da1, k1, c1, m1, i1, True, grads, 1)
         _wgrad(C, blk.conv1, x, d1, grads, 0)
@@ -142,11 +148,11 @@ class _BottleneckFn(torch.autograd.Function):
             dd = _bn_bwd(C, blk.downsample[1], dout, k3, cd, md, isd, True, grads, 10)   # "relu" = the join's mask
             _wgrad(C, dconv, x, dd, grads, 9)
             if need_dx:
-                dxd = C.conv_dgrad(dd, C.transpose_filter(dconv.weight_lp), x.shape[1], x.shape[2], dconv.stride, 0, None, None)
-                dx = C.conv_dgrad(d1, C.transpose_filter(blk.conv1.weight_lp), x.shape[1], x.shape[2], 1, 0, dxd, None)
+                dxd = C.conv_dgrad(dd, _wt(C, dconv), x.shape[1], x.shape[2], dconv.stride, 0, None, None)
+                dx = C.conv_dgrad(d1, _wt(C, blk.conv1), x.shape[1], x.shape[2], 1, 0, dxd, None)
         elif need_dx:
             # identity shortcut: the masked residual gradient is added in the dgrad epilogue
-            dx = C.conv_dgrad(d1, C.transpose_filter(blk.conv1.weight_lp), x.shape[1], x.shape[2], 1, 0, dout, k3)
+            dx = C.conv_dgrad(d1, _wt(C, blk.conv1), x.shape[1], x.shape[2], 1, 0, dout, k3)
         return (dx, None, *grads)
 
 

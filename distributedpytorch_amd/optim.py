@@ -65,6 +65,7 @@ class FusedSGD:
             # ONE launch over the whole flat buffer
             C.sgd_momentum(f.master, f.grad, self.momentum_buf, f.lp, self.lr, self.momentum, self.segments[0][2], gs,
                            zero_grad, self.nesterov, self._seg_ends, self._seg_wd)
+            f.refresh_transposed()          # conv filters' [C,R,S,K] twins for the next backward (one launch)
         else:
             for a, b, wd in self.segments:
                 p, g = f.master[a:b], f.grad[a:b]
@@ -131,6 +132,7 @@ class FusedAdamW:
             from .ops import _ext
             _ext.load().adamw(f.master, f.grad, self.m, self.v, f.lp, self.lr, b1, b2, self.eps, self.weight_decay, gs,
                               self.steps, zero_grad)
+            f.refresh_transposed()
         else:
             g = f.grad * gs
             self.m.mul_(b1).add_(g, alpha=1 - b1)

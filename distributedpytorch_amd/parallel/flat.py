@@ -69,6 +69,26 @@ class FlatParams:
             g = self.grad[off:off + n].view(p.shape)
             p.grad = g
             self._grad_views[id(p)] = g
+        # transposed twin of the bf16 shadow for conv filters ([C,R,S,K], what dgrad consumes), refreshed by ONE
+        # batched kernel after every optimizer step instead of one transpose launch per layer per backward
+        self.lp_t = None
+        self._tr_table = None
+        self._tr_tiles = 0
+        if self.lp is not None:
+            rows, tiles = [], 0
+            for mod in module.modules():
+                w = getattr(mod, "weight", None)
+                if hasattr(mod, "weight_lp_t") and isinstance(w, nn.Parameter) and w.dim() == 4:
+                    i = next((k for k, q in enumerate(self.params) if q is w), None)
+                    if i is None:
+                        continue
+                    K, R, S, C = w.shape
+                    rows.append([offsets[i], offsets[i], K, R * S, C, tiles])
+                    tiles += ((K + 31) // 32) * ((C + 31) // 32) * R * S
+            if rows:
+                self.lp_t = torch.zeros(self.total, dtype=self.lp_dtype, device=device)
+                self._tr_table = torch.tensor(rows, dtype=torch.int64, device=device)
+                self._tr_tiles = tiles
         self.refresh_lp()
         self._bind_shadows()
 
@@ -97,12 +117,23 @@ class FlatParams:
                     i = index[id(p)]
                     off = self.offsets[i]
                     setattr(mod, attr, self.lp[off:off + p.numel()].view(p.shape))
+                    if pname == "weight" and self.lp_t is not None and hasattr(mod, "weight_lp_t") and p.dim() == 4:
+                        K, R, S, C = p.shape
+                        mod.weight_lp_t = self.lp_t[off:off + p.numel()].view(C, R, S, K)
 
     def refresh_lp(self) -> None:
         if self.lp is None:
             return
         from ..ops import _ext
         _ext.load().cast_f32_to_bf16(self.master, self.lp)
+        self.refresh_transposed()
+
+    def refresh_transposed(self) -> None:
+        """Re-derive the transposed conv filters from the bf16 shadow (one launch for the whole model)."""
+        if self.lp_t is None:
+            return
+        from ..ops import _ext
+        _ext.load().transpose_filters_batched(self.lp, self.lp_t, self._tr_table, self._tr_tiles)
 
     # ------------------------------------------------------------------ grads
     def zero_grad(self) -> None:
