@@ -41,15 +41,22 @@ def _data(shape, classes, n, seed=7):
     return torch.randn(n, *shape, generator=g), torch.randint(0, classes, (n,), generator=g)
 
 
-def dp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, bucket_kb, steps, mode="hooks"):
-    """Each rank takes its shard of ONE global batch; writes reduced grads + params."""
-    comm = dcomm.init_process_group("gloo", url, global_rank, world_size, 60.0, torch.device("cpu"))
+def dp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, bucket_kb, steps, mode="hooks", backend="gloo"):
+    """Each rank takes its shard of ONE global batch; writes reduced grads + params.
+    backend "nccl": one GPU per rank over RCCL (multi-GPU boxes only; tests/test_multi_gpu.py)."""
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        device = torch.device("cpu")
+    comm = dcomm.init_process_group(backend, url, global_rank, world_size, 60.0, device)
     model, loss_fn, shape, classes = _make_model(model_name)
+    model = model.to(device)
     n_global = 8 * world_size
     x, y = _data(shape, classes, n_global)
     per = n_global // world_size
-    xs, ys = x[global_rank * per:(global_rank + 1) * per], y[global_rank * per:(global_rank + 1) * per]
-    dp = DataParallel(model, comm, bucket_mb=bucket_kb / 1024.0, first_bucket_mb=bucket_kb / 4096.0)
+    xs, ys = x[global_rank * per:(global_rank + 1) * per].to(device), y[global_rank * per:(global_rank + 1) * per].to(device)
+    dp = DataParallel(model, comm, bucket_mb=bucket_kb / 1024.0, first_bucket_mb=bucket_kb / 4096.0, use_lp=(model_name != "mnist"))
     opt = FusedSGD(dp.flat, lr=0.05, momentum=0.5)
     opt.grad_scale = dp.grad_scale
     losses = []
@@ -64,13 +71,15 @@ def dp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, buc
             loss.backward()
             dp.finish()
         if s == 0:
-            g = dp.flat.grad.clone() * dp.grad_scale
+            if device.type == "cuda":
+                torch.cuda.synchronize()
+            g = dp.flat.grad.clone().cpu() * dp.grad_scale
             torch.save({n: g[dp.flat.offsets[i]:dp.flat.offsets[i] + p.numel()].view(p.shape).clone()
                         for i, (n, p) in enumerate(zip(dp.flat.names, dp.flat.params))},
                        os.path.join(out_dir, f"grads_{global_rank}.pt"))
         opt.step()
         losses.append(float(loss.detach()))
-    torch.save({"losses": losses, "params": {n: p.detach().clone() for n, p in model.named_parameters()},
+    torch.save({"losses": losses, "params": {n: p.detach().cpu().clone() for n, p in model.named_parameters()},
                 "buckets": len(dp.buckets), "calls": dp.stats["allreduce_calls"]},
                os.path.join(out_dir, f"final_{global_rank}.pt"))
     comm.barrier()
