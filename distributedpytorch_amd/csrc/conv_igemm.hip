@@ -49,8 +49,14 @@ __device__ __forceinline__ int swz4(int row) {  // conflict-free chunk swizzle f
 // after the barrier, re-issue t+2 at once), <= 128 VGPRs = 4 waves per SIMD: better for grids of very
 // many short workgroups, where occupancy hides more than prefetch depth does (use_ring() below).
 // Accumulators stay in VGPRs in both (no AGPR copies).
-template <int WP, int WC, int MODE, bool ONE, bool RING>
-__global__ __launch_bounds__(256, RING ? ((WP == 4 && !ONE) ? 2 : 3) : 4) void conv_igemm_kernel(ConvArgs a, int tiles_c, long M_all, int Kg_all) {
+//   STG 0: one register set, 4 waves/SIMD;  STG 1: register ring, 3 waves/SIMD;
+//   STG 2: LDS-DMA (buffer_load ... lds): the gather lands in LDS without passing through VGPRs or
+//          ds_write_b128 (13 LDS-pipe cycles per KiB) - with register staging the LDS pipe, not the MFMA pipe,
+//          is the busiest unit of this kernel (PMC: SQ_ACTIVE_INST_LDS 71 % on a 768-deep GEMM).  The lane ->
+//          LDS slot map of the DMA is linear, so each lane fetches the chunk that belongs in its slot
+//          (the XOR swizzle moves to the source address); padding / tile edges still read zeros by range check.
+template <int WP, int WC, int MODE, bool ONE, int STG>
+__global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) void conv_igemm_kernel(ConvArgs a, int tiles_c, long M_all, int Kg_all) {
     constexpr int BP = WP * 64, BC = WC * 64;
     constexpr int XR = BP * CHUNKS / 256;  // x rows per thread
     constexpr int WR = BC * CHUNKS / 256;  // w rows per thread
@@ -137,7 +143,10 @@ __global__ __launch_bounds__(256, RING ? ((WP == 4 && !ONE) ? 2 : 3) : 4) void c
         const int co = c0 + lrow + i * 64;
         wb[i] = co < a.K ? (unsigned)co * (unsigned)KgW * 2u : wbytes;
     }
-    int kr = 0, ks = 0, kc = chunk * 8;  // (tap row, tap col, channel) of this thread's chunk
+    const int wsw = chunk ^ swz4(lrow);  // (row>>2)&3 is the same for lrow + 64*i
+    constexpr bool RING = STG == 1;
+    // register staging: load chunk `chunk`, store it to slot `wsw`;  DMA: slot = lane order = `chunk`, so load chunk `wsw`
+    int kr = 0, ks = 0, kc = (STG == 2 ? wsw : chunk) * 8;  // (tap row, tap col, channel) of this thread's chunk
     if (!ONE) while (kc >= a.C) { kc -= a.C; if (++ks == ns) { ks = 0; ++kr; } }
 
     // Two register sets form a ring: the loads of tile t+2 are issued before the MFMAs of tile
@@ -172,7 +181,6 @@ __global__ __launch_bounds__(256, RING ? ((WP == 4 && !ONE) ? 2 : 3) : 4) void c
         }                                                                                        \
     }
 
-    const int wsw = chunk ^ swz4(lrow);  // (row>>2)&3 is the same for lrow + 64*i
 #define DPA_STORE_TILE(BUF, XREG, WREG)                                                          \
     {                                                                                            \
         unsigned char* xs_ = smem + (BUF) * STAGE_BYTES;                                         \
@@ -181,6 +189,38 @@ __global__ __launch_bounds__(256, RING ? ((WP == 4 && !ONE) ? 2 : 3) : 4) void c
             *(u32x4*)(xs_ + ((lrow + i * 64) * CHUNKS + wsw) * 16) = XREG[i];                    \
         _Pragma("unroll") for (int i = 0; i < WR; ++i)                                           \
             *(u32x4*)(ws_ + ((lrow + i * 64) * CHUNKS + wsw) * 16) = WREG[i];                    \
+    }
+
+    // LDS-DMA of one K tile: wave w fills rows 16w .. 16w+15 (+ 64 i) of each operand, 1 KiB per instruction
+    typedef __attribute__((address_space(3))) void* lds_void_ptr;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#define DPA_DMA_TILE(BUF)                                                                        \
+    {                                                                                            \
+        unsigned char* xs_ = smem + (BUF) * STAGE_BYTES + wave_u * (16 * BK * 2);                \
+        unsigned char* ws_ = xs_ + BP * BK * 2;                                                  \
+        if (ONE) {                                                                               \
+            const unsigned kadd = kc < Kg ? (unsigned)kc * 2u : xbytes;                          \
+            _Pragma("unroll") for (int i = 0; i < XR; ++i)                                       \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_ptr)(xs_ + i * (64 * BK * 2)), 16, xb[i] + kadd, 0, 0, 0); \
+            _Pragma("unroll") for (int i = 0; i < WR; ++i)                                       \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_ptr)(ws_ + i * (64 * BK * 2)), 16, wb[i] + (unsigned)kc * 2u, 0, 0, 0); \
+            kc += BK;                                                                            \
+        } else {                                                                                 \
+            const bool kok = kr < nr;                                                            \
+            _Pragma("unroll") for (int i = 0; i < XR; ++i) {                                     \
+                int hi, wi;                                                                      \
+                if (MODE == 0) { hi = hi0[i] + kr; wi = wi0[i] + ks; }                           \
+                else           { hi = hi0[i] - kr; wi = wi0[i] - ks; }                           \
+                const bool ok = kok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W; \
+                const unsigned off = ((xb[i] + (unsigned)(hi * a.W + wi)) * (unsigned)a.C + (unsigned)kc) * 2u; \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_ptr)(xs_ + i * (64 * BK * 2)), 16, ok ? off : xbytes, 0, 0, 0); \
+            }                                                                                    \
+            const unsigned wk = (unsigned)(((r0 + tstep * kr) * a.S + (s0 + tstep * ks)) * a.C + kc) * 2u; \
+            _Pragma("unroll") for (int i = 0; i < WR; ++i)                                       \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_ptr)(ws_ + i * (64 * BK * 2)), 16, kok ? wb[i] + wk : wbytes, 0, 0, 0); \
+            kc += BK;                                                                            \
+            while (kc >= a.C) { kc -= a.C; if (++ks == ns) { ks = 0; ++kr; } }                   \
+        }                                                                                        \
     }
 
     floatx4 acc[4][4];
@@ -209,7 +249,19 @@ __global__ __launch_bounds__(256, RING ? ((WP == 4 && !ONE) ? 2 : 3) : 4) void c
 
     // Loads past the last K tile fall outside the buffers (zeros) and their LDS image is never
     // read, so the loop body carries no conditions.
-    if (RING) {
+    if (STG == 2) {
+        // tile kt+1 is DMA-ed into the other buffer while tile kt is multiplied; the DMA counts on vmcnt
+        DPA_DMA_TILE(0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            DPA_DMA_TILE((kt + 1) & 1)         // tile kt + 1 (its buffer was last read before the barrier)
+            __builtin_amdgcn_sched_barrier(0);
+            DPA_COMPUTE(kt & 1)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else if (RING) {
         DPA_LOAD_TILE(xr0, wr0)
         DPA_LOAD_TILE(xr1, wr1)
         DPA_STORE_TILE(0, xr0, wr0)
@@ -443,10 +495,11 @@ __global__ __launch_bounds__(256, RING ? ((WP == 4 && !ONE) ? 2 : 3) : 4) void c
 }
 
 #undef DPA_LOAD_TILE
+#undef DPA_DMA_TILE
 #undef DPA_STORE_TILE
 #undef DPA_COMPUTE
 
-template <int WP, int WC, bool ONE, bool RING>
+template <int WP, int WC, bool ONE, int STG>
 void launch(const ConvArgs& a, hipStream_t st) {
     const long M = (long)a.N * a.Ho * a.Wo;
     const int Kg = a.R * a.S * a.C;
@@ -454,15 +507,15 @@ void launch(const ConvArgs& a, hipStream_t st) {
     dim3 block(256);
     if (a.mode == 0) {
         const int tiles_p = (int)((M + WP * 64 - 1) / (WP * 64));
-        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 0, ONE, RING>), dim3(tiles_p * tiles_c), block, 0, st, a, tiles_c, M, Kg);
+        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 0, ONE, STG>), dim3(tiles_p * tiles_c), block, 0, st, a, tiles_c, M, Kg);
     } else if (a.stride == 1) {
         const int tiles_p = (int)((M + WP * 64 - 1) / (WP * 64));
-        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 1, ONE, RING>), dim3(tiles_p * tiles_c), block, 0, st, a, tiles_c, M, Kg);
+        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 1, ONE, STG>), dim3(tiles_p * tiles_c), block, 0, st, a, tiles_c, M, Kg);
     } else {
         const int st_ = a.stride;
         const long mc = (long)a.N * ((a.Ho + st_ - 1) / st_) * ((a.Wo + st_ - 1) / st_);   // largest parity class
         const int tiles_p = (int)((mc + WP * 64 - 1) / (WP * 64));
-        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 2, false, RING>), dim3(tiles_p * tiles_c, st_ * st_), block, 0, st, a, tiles_c, M, Kg);
+        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 2, false, STG>), dim3(tiles_p * tiles_c, st_ * st_), block, 0, st, a, tiles_c, M, Kg);
     }
 }
 
@@ -470,10 +523,10 @@ void launch(const ConvArgs& a, hipStream_t st) {
 
 int conv_stats_rows(long M) { (void)M; return 32; }
 
-// DPA_IGEMM_RING=0/1 forces a variant (experiments); default: by resident-workgroup arithmetic.
-static bool use_ring(const ConvArgs& a) {
-    static const int forced = [] { const char* e = getenv("DPA_IGEMM_RING"); return e ? atoi(e) : -1; }();
-    if (forced >= 0) return forced != 0;
+// DPA_IGEMM_STG=0/1/2 forces a staging variant (experiments).
+static int staging(const ConvArgs& a) {
+    static const int forced = [] { const char* e = getenv("DPA_IGEMM_STG"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced;
     const long M = (long)a.N * a.Ho * a.Wo;
     const bool wide = a.K <= 64;
     const long bp = wide ? 256 : 128, bc = wide ? 64 : 128;
@@ -482,20 +535,22 @@ static bool use_ring(const ConvArgs& a) {
     // Measured on the ResNet-50 shapes (scripts/bench_conv.py, DPA_IGEMM_RING=0/1): grids of many short
     // workgroups (layer-1 sized, >= ~16 per CU) gain 5-10 % from the 4th resident wave, long-K grids with
     // few workgroups per CU lose up to 15 % without the deeper prefetch.
-    return blocks < 4096;
+    return blocks < 4096 ? 1 : 0;
 }
 
 void conv_igemm(const ConvArgs& a, hipStream_t st) {
     // 1x1 / no padding: plain GEMM gather (strided fprop included; strided dgrad goes by parity class)
     const bool one = a.R == 1 && a.S == 1 && a.pad == 0 && (a.mode == 0 || a.stride == 1);
-    const bool ring = use_ring(a);
-    if (a.K <= 64) {
-        if (one) { if (ring) launch<4, 1, true, true>(a, st); else launch<4, 1, true, false>(a, st); }
-        else     { if (ring) launch<4, 1, false, true>(a, st); else launch<4, 1, false, false>(a, st); }
-    } else {
-        if (one) { if (ring) launch<2, 2, true, true>(a, st); else launch<2, 2, true, false>(a, st); }
-        else     { if (ring) launch<2, 2, false, true>(a, st); else launch<2, 2, false, false>(a, st); }
+    const int stg = staging(a);
+#define DPA_DISPATCH(WP_, WC_, ONE_)                                         \
+    switch (stg) {                                                           \
+        case 0: launch<WP_, WC_, ONE_, 0>(a, st); break;                     \
+        case 1: launch<WP_, WC_, ONE_, 1>(a, st); break;                     \
+        default: launch<WP_, WC_, ONE_, 2>(a, st); break;                    \
     }
+    if (a.K <= 64) { if (one) DPA_DISPATCH(4, 1, true) else DPA_DISPATCH(4, 1, false) }
+    else           { if (one) DPA_DISPATCH(2, 2, true) else DPA_DISPATCH(2, 2, false) }
+#undef DPA_DISPATCH
 }
 
 // ------------------------------------------------------------------ filter transpose

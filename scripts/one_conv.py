@@ -13,7 +13,7 @@ H, Cin, K, R, s, p = (int(v) for v in sys.argv[1:7])
 what = sys.argv[7]
 iters = int(sys.argv[8]) if len(sys.argv) > 8 else 3
 C = _ext.load()
-N = 256
+N = int(os.environ.get("BATCH", "256"))
 Ho = (H + 2 * p - R) // s + 1
 x = torch.randn(N, H, H, Cin, device="cuda").to(torch.bfloat16)
 w = (torch.randn(K, R, R, Cin, device="cuda") * 0.05).to(torch.bfloat16)
