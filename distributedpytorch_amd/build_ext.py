@@ -68,6 +68,18 @@ def _run(cmd):
     return r.stdout
 
 
+def _check_loads(so: Path) -> None:
+    """dlopen the fresh library in a child interpreter: an unresolved symbol (e.g. a kernel whose host
+    stub the compiler dropped) must fail the build here, not the first GPU run."""
+    code = ("import importlib.util, sys, torch\n"
+            f"spec = importlib.util.spec_from_file_location('distributedpytorch_amd.{MODULE}', r'{so}')\n"
+            "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n")
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        so.unlink(missing_ok=True)
+        raise RuntimeError(f"{so.name} was linked but does not load:\n{r.stdout[-2000:]}")
+
+
 def build(verbose: bool = True, jobs: int = 8) -> Path:
     BUILD.mkdir(parents=True, exist_ok=True)
     hipcc = _hipcc()
@@ -113,6 +125,7 @@ def build(verbose: bool = True, jobs: int = 8) -> Path:
         _run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", *map(str, objs), "-o", str(out),
               f"-L{lib_dir}", "-lc10", "-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10_hip", "-ltorch_hip",
               "-lamdhip64", "-lrccl", f"-Wl,-rpath,{lib_dir}"])   # the RCCL torch itself loads (one RCCL per process)
+        _check_loads(out)
         stamp.write_text(key)
         # drop objects of older source versions
         keep = {o.name for o in objs}

@@ -39,7 +39,7 @@ std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::opti
     TORCH_CHECK(stride >= 1 && pad >= 0, "bad stride/pad");
     const int64_t Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     TORCH_CHECK(Ho > 0 && Wo > 0, "conv_fprop: empty output");
-    TORCH_CHECK(x.numel() < (1ll << 30) && w.numel() < (1ll << 30) && N * Ho * Wo < (1ll << 31),
+    TORCH_CHECK(x.numel() < (1ll << 30) && w.numel() < (1ll << 30) && N * Ho * Wo * K < (1ll << 31) - 16,
                 "conv_fprop: operands must have fewer than 2^31 elements (32-bit gather offsets)");
     Guard g(x);
     Tensor y = torch::empty({N, Ho, Wo, K}, x.options());
@@ -83,7 +83,7 @@ static dpa::ConvArgs fused_args(const Tensor& x, const Tensor& w, int64_t stride
     const int64_t K = w.size(0), R = w.size(1), S = w.size(2);
     const int64_t Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     TORCH_CHECK(C % 8 == 0 && K % 8 == 0 && Ho > 0 && Wo > 0, who, ": bad geometry");
-    TORCH_CHECK(x.numel() < (1ll << 30) && w.numel() < (1ll << 30) && N * Ho * Wo < (1ll << 31), who, ": operands too large");
+    TORCH_CHECK(x.numel() < (1ll << 30) && w.numel() < (1ll << 30) && N * Ho * Wo * K < (1ll << 31) - 16, who, ": operands too large");
     dpa::ConvArgs a{};
     a.x = x.data_ptr(); a.w = w.data_ptr();
     a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.Ho = Ho; a.Wo = Wo;
@@ -193,7 +193,7 @@ Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int6
     dpa::ConvArgs a{};
     a.x = dy.data_ptr(); a.w = wt.data_ptr(); a.y = dx.data_ptr(); a.bias = nullptr; a.stats = nullptr;
     a.stats_rows = 0; a.addend = nullptr;
-    TORCH_CHECK(dy.numel() < (1ll << 30) && wt.numel() < (1ll << 30) && N * H * W < (1ll << 31),
+    TORCH_CHECK(dy.numel() < (1ll << 30) && wt.numel() < (1ll << 30) && N * H * W * C < (1ll << 31) - 16,
                 "conv_dgrad: operands must have fewer than 2^30 elements");
     if (addend.has_value() && addend->defined()) {
         CHECK_BF16((*addend));

@@ -43,6 +43,12 @@ __device__ __forceinline__ int swz4(int row) {  // conflict-free chunk swizzle f
     return (0x78 >> (2 * ((row >> 2) & 3))) & 3;  // {0,2,3,1}[(row>>2)&3]
 }
 
+// 16 B per lane from a buffer descriptor straight into LDS (lane-linear destination from the wave-uniform `lds`)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* lds, unsigned voffset) {
+    typedef __attribute__((address_space(3))) void* lds_void_ptr;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)lds, 16, voffset, 0, 0, 0);
+}
+
 // ONE: 1x1 filter, no padding (a plain GEMM over gathered rows): no tap arithmetic in the loop.
 // Two pipelining variants.  RING: two register sets, loads two tiles ahead, 3 waves per SIMD (<= 168
 // VGPRs; the 256x64 general-gather variant runs at 2).  !RING: one register set (write tile t+1 right
@@ -192,7 +198,6 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
     }
 
     // LDS-DMA of one K tile: wave w fills rows 16w .. 16w+15 (+ 64 i) of each operand, 1 KiB per instruction
-    typedef __attribute__((address_space(3))) void* lds_void_ptr;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 #define DPA_DMA_TILE(BUF)                                                                        \
     {                                                                                            \
@@ -201,9 +206,9 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
         if (ONE) {                                                                               \
             const unsigned kadd = kc < Kg ? (unsigned)kc * 2u : xbytes;                          \
             _Pragma("unroll") for (int i = 0; i < XR; ++i)                                       \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_ptr)(xs_ + i * (64 * BK * 2)), 16, xb[i] + kadd, 0, 0, 0); \
+                dma16(xrs, xs_ + i * (64 * BK * 2), xb[i] + kadd); \
             _Pragma("unroll") for (int i = 0; i < WR; ++i)                                       \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_ptr)(ws_ + i * (64 * BK * 2)), 16, wb[i] + (unsigned)kc * 2u, 0, 0, 0); \
+                dma16(wrs, ws_ + i * (64 * BK * 2), wb[i] + (unsigned)kc * 2u); \
             kc += BK;                                                                            \
         } else {                                                                                 \
             const bool kok = kr < nr;                                                            \
@@ -213,11 +218,11 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
                 else           { hi = hi0[i] - kr; wi = wi0[i] - ks; }                           \
                 const bool ok = kok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W; \
                 const unsigned off = ((xb[i] + (unsigned)(hi * a.W + wi)) * (unsigned)a.C + (unsigned)kc) * 2u; \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_ptr)(xs_ + i * (64 * BK * 2)), 16, ok ? off : xbytes, 0, 0, 0); \
+                dma16(xrs, xs_ + i * (64 * BK * 2), ok ? off : xbytes); \
             }                                                                                    \
             const unsigned wk = (unsigned)(((r0 + tstep * kr) * a.S + (s0 + tstep * ks)) * a.C + kc) * 2u; \
             _Pragma("unroll") for (int i = 0; i < WR; ++i)                                       \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_ptr)(ws_ + i * (64 * BK * 2)), 16, kok ? wb[i] + wk : wbytes, 0, 0, 0); \
+                dma16(wrs, ws_ + i * (64 * BK * 2), kok ? wb[i] + wk : wbytes); \
             kc += BK;                                                                            \
             while (kc >= a.C) { kc -= a.C; if (++ks == ns) { ks = 0; ++kr; } }                   \
         }                                                                                        \
@@ -294,6 +299,55 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
             DPA_COMPUTE(kt & 1)
             __syncthreads();
         }
+    }
+
+    // ---- write-out geometry, and an early issue of everything the write-out READS from memory
+    //      (residual / gradient operand and its bit mask).  Issued here, the loads are in flight
+    //      while the accumulators are staged and the statistics run; issued inside the write-out
+    //      loop, each of the 8 passes paid a full memory round trip (measured: the fused epilogues
+    //      streamed at < 4 TB/s where the stand-alone BatchNorm kernels reach 5). ----
+    constexpr int CPR = BC / 8;        // chunks per row
+    constexpr int RPP = 256 / CPR;     // rows per pass
+    constexpr int NPASS = BP / RPP;
+    const int och = tid % CPR, orow = tid / CPR;
+    const int co = c0 + och * 8;       // this thread's 8 channels are the same in every pass
+    unsigned eoff[NPASS];              // element offset of the 8 channels in the output; ~0u = nothing to write
+#pragma unroll
+    for (int pss = 0; pss < NPASS; ++pss) {
+        const long m = m0 + pss * RPP + orow;
+        unsigned pix = (unsigned)m;
+        if (MODE == 2) {
+            const unsigned mm = m < M ? (unsigned)m : 0u;
+            const unsigned n = mm / (unsigned)PHW;
+            const unsigned rem = mm - n * (unsigned)PHW;
+            const unsigned hh = rem / (unsigned)PW, ww = rem - hh * (unsigned)PW;
+            pix = (n * (unsigned)a.Ho + hh * (unsigned)a.stride + (unsigned)ph0) * (unsigned)a.Wo + ww * (unsigned)a.stride + (unsigned)pw0;
+        }
+        eoff[pss] = (m < M && co < a.K) ? pix * (unsigned)a.K + (unsigned)co : ~0u;   // output < 2^31 elements (host check)
+    }
+    const bool epi_on = MODE == 0 && a.epi != 0;
+    const void* pre_src = epi_on ? a.ep_src : a.addend;
+    const unsigned char* pre_msk = epi_on ? (a.epi == 1 ? nullptr : a.ep_mask_in) : a.addend_mask;
+    u32x4 pre[NPASS];
+    unsigned pmk[NPASS];
+    if (pre_src != nullptr) {
+        const unsigned ybytes = (unsigned)a.N * a.Ho * a.Wo * a.K * 2u;
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)pre_src, 0, ybytes, 0x00020000);
+#pragma unroll
+        for (int pss = 0; pss < NPASS; ++pss)
+            pre[pss] = __builtin_amdgcn_raw_buffer_load_b128(srs, eoff[pss] != ~0u ? eoff[pss] * 2u : 0xFFFFFFF0u, 0, 0);
+        if (pre_msk != nullptr) {
+            const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void*)pre_msk, 0, ybytes >> 4, 0x00020000);
+#pragma unroll
+            for (int pss = 0; pss < NPASS; ++pss)
+                pmk[pss] = __builtin_amdgcn_raw_buffer_load_b8(mrs, eoff[pss] != ~0u ? eoff[pss] >> 3 : 0xFFFFFFF0u, 0, 0);
+        } else {
+#pragma unroll
+            for (int pss = 0; pss < NPASS; ++pss) pmk[pss] = 0xFFu;
+        }
+    } else {
+#pragma unroll
+        for (int pss = 0; pss < NPASS; ++pss) { pre[pss] = u32x4{0u, 0u, 0u, 0u}; pmk[pss] = 0u; }
     }
 
     // ---- epilogue: bias/activation, stage the bf16 tile in LDS ----
@@ -381,11 +435,6 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
 
     // ---- coalesced write-out: 16 B per lane over full output rows ----
     unsigned short* yg = (unsigned short*)a.y;
-    const unsigned short* addg = (const unsigned short*)a.addend;
-    constexpr int CPR = BC / 8;        // chunks per row
-    constexpr int RPP = 256 / CPR;     // rows per pass
-    const int och = tid % CPR, orow = tid / CPR;
-    const int co = c0 + och * 8;       // this thread's 8 channels are the same in every pass
 
     // Fused BatchNorm epilogues (a.epi != 0; MODE 0 only).  They let a cheap 1x1 conv in front of a
     // BatchNorm be RECOMPUTED instead of stored: the raw conv output never goes to memory.
@@ -393,8 +442,7 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
     //   epi 2: no output; adds sum(g), sum(g * c) per channel into ep_stats        (BN backward, reduction pass)
     //   epi 3: y = ep_a[ch] * g + ep_b[ch] * c + ep_c[ch]                          (BN backward, apply pass)
     // with c = the bf16-rounded conv output of this tile, g = ep_src under the bit mask ep_mask_in.
-    if (MODE == 0 && a.epi != 0) {
-        const unsigned short* srcg = (const unsigned short*)a.ep_src;
+    if (epi_on) {
         float ea[8], eb[8], ec[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -407,14 +455,13 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s8[j] = 0.f; q8[j] = 0.f; }
 #pragma unroll
-        for (int pss = 0; pss < BP / RPP; ++pss) {
+        for (int pss = 0; pss < NPASS; ++pss) {
             const int row = pss * RPP + orow;
-            const long m = m0 + row;
-            if (m < M && co < a.K) {
-                const long e0 = m * a.K + co;
+            if (eoff[pss] != ~0u) {
+                const size_t e0 = eoff[pss];
                 float c[8], g[8];
                 { const uint4 v = *(const uint4*)(cs + row * CS + och * 8); unpack8(v, c); }
-                { const uint4 v = *(const uint4*)(srcg + e0); unpack8(v, g); }
+                unpack8(__builtin_bit_cast(uint4, pre[pss]), g);
                 if (a.epi == 1) {
                     unsigned mk = 0;
 #pragma unroll
@@ -426,7 +473,7 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
                     *(uint4*)(yg + e0) = pack8(c);
                     a.ep_mask_out[e0 >> 3] = (unsigned char)mk;
                 } else {
-                    const unsigned mk = a.ep_mask_in[e0 >> 3];
+                    const unsigned mk = pmk[pss];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) g[j] = ((mk >> j) & 1u) ? g[j] : 0.f;
                     if (a.epi == 2) {
@@ -464,32 +511,19 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
     if (yg == nullptr) return;          // statistics-only pass
 
 #pragma unroll
-    for (int pss = 0; pss < BP / RPP; ++pss) {
+    for (int pss = 0; pss < NPASS; ++pss) {
         const int row = pss * RPP + orow;
-        const long m = m0 + row;
-        if (m < M && co < a.K) {
-            long orow_g = m;           // output pixel index in [N][Ho][Wo]
-            if (MODE == 2) {
-                const int n = (int)(m / PHW);
-                const int rem = (int)(m - (long)n * PHW);
-                const int hh = rem / PW, ww = rem - hh * PW;
-                orow_g = ((long)n * a.Ho + hh * a.stride + ph0) * a.Wo + ww * a.stride + pw0;
-            }
+        if (eoff[pss] != ~0u) {
             uint4 v = *(const uint4*)(cs + row * CS + och * 8);
-            if (addg != nullptr) {
-                const uint4 ad = *(const uint4*)(addg + orow_g * a.K + co);
+            if (pre_src != nullptr) {
                 float f[8], g[8];
-                unpack8(v, f); unpack8(ad, g);
-                if (a.addend_mask != nullptr) {
-                    const unsigned mk = a.addend_mask[(orow_g * a.K + co) >> 3];
+                unpack8(v, f); unpack8(__builtin_bit_cast(uint4, pre[pss]), g);
+                const unsigned mk = pmk[pss];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) g[j] = ((mk >> j) & 1u) ? g[j] : 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] += g[j];
+                for (int j = 0; j < 8; ++j) f[j] += ((mk >> j) & 1u) ? g[j] : 0.f;
                 v = pack8(f);
             }
-            *(uint4*)(yg + orow_g * a.K + co) = v;
+            *(uint4*)(yg + (size_t)eoff[pss]) = v;
         }
     }
 }
@@ -499,24 +533,28 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
 #undef DPA_STORE_TILE
 #undef DPA_COMPUTE
 
-template <int WP, int WC, bool ONE, int STG>
-void launch(const ConvArgs& a, hipStream_t st) {
+template <int WP, int WC, int STG>
+void launch_by_parity(const ConvArgs& a, hipStream_t st) {      // strided dgrad: one grid row per pixel parity class
     const long M = (long)a.N * a.Ho * a.Wo;
     const int Kg = a.R * a.S * a.C;
     const int tiles_c = (a.K + WC * 64 - 1) / (WC * 64);
-    dim3 block(256);
-    if (a.mode == 0) {
-        const int tiles_p = (int)((M + WP * 64 - 1) / (WP * 64));
-        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 0, ONE, STG>), dim3(tiles_p * tiles_c), block, 0, st, a, tiles_c, M, Kg);
-    } else if (a.stride == 1) {
-        const int tiles_p = (int)((M + WP * 64 - 1) / (WP * 64));
-        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 1, ONE, STG>), dim3(tiles_p * tiles_c), block, 0, st, a, tiles_c, M, Kg);
-    } else {
-        const int st_ = a.stride;
-        const long mc = (long)a.N * ((a.Ho + st_ - 1) / st_) * ((a.Wo + st_ - 1) / st_);   // largest parity class
-        const int tiles_p = (int)((mc + WP * 64 - 1) / (WP * 64));
-        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 2, false, STG>), dim3(tiles_p * tiles_c, st_ * st_), block, 0, st, a, tiles_c, M, Kg);
-    }
+    const int st_ = a.stride;
+    const long mc = (long)a.N * ((a.Ho + st_ - 1) / st_) * ((a.Wo + st_ - 1) / st_);   // largest parity class
+    const int tiles_p = (int)((mc + WP * 64 - 1) / (WP * 64));
+    hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 2, false, STG>), dim3(tiles_p * tiles_c, st_ * st_), dim3(256), 0, st, a, tiles_c, M, Kg);
+}
+
+template <int WP, int WC, bool ONE, int STG>
+void launch(const ConvArgs& a, hipStream_t st) {
+    if (a.mode != 0 && a.stride != 1) { launch_by_parity<WP, WC, STG>(a, st); return; }
+    const long M = (long)a.N * a.Ho * a.Wo;
+    const int Kg = a.R * a.S * a.C;
+    const int tiles_c = (a.K + WC * 64 - 1) / (WC * 64);
+    const int tiles_p = (int)((M + WP * 64 - 1) / (WP * 64));
+    if (a.mode == 0)
+        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 0, ONE, STG>), dim3(tiles_p * tiles_c), dim3(256), 0, st, a, tiles_c, M, Kg);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 1, ONE, STG>), dim3(tiles_p * tiles_c), dim3(256), 0, st, a, tiles_c, M, Kg);
 }
 
 }  // namespace
