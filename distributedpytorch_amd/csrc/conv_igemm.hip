@@ -43,10 +43,22 @@ __device__ __forceinline__ int swz4(int row) {  // conflict-free chunk swizzle f
     return (0x78 >> (2 * ((row >> 2) & 3))) & 3;  // {0,2,3,1}[(row>>2)&3]
 }
 
-// 16 B per lane from a buffer descriptor straight into LDS (lane-linear destination from the wave-uniform `lds`)
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* lds, unsigned voffset) {
-    typedef __attribute__((address_space(3))) void* lds_void_ptr;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)lds, 16, voffset, 0, 0, 0);
+// 16 B per lane from a buffer descriptor straight into LDS (lane-linear destination from the wave-uniform `lds`).
+// COUNTED = false: the compiler's builtin; it then treats every later LDS read as dependent on the DMA and
+// drains vmcnt to 0 before each barrier.  COUNTED = true: the same instruction issued from inline assembly, which
+// leaves the vmcnt bookkeeping to the kernel (counted waits, two tiles in flight).  Loads complete in issue
+// order, so compiler-inserted waits for its own loads only ever become stricter by the ones it cannot see.
+template <bool COUNTED>
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, u32x4 rs4, unsigned char* lds, unsigned voffset) {
+    if (COUNTED) {
+        typedef __attribute__((address_space(3))) unsigned char* lds_byte_ptr;
+        const unsigned lds_addr = (unsigned)(unsigned long long)(lds_byte_ptr)lds;
+        asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                     :: "v"(voffset), "s"(rs4), "s"(lds_addr) : "memory", "m0");
+    } else {
+        typedef __attribute__((address_space(3))) void* lds_void_ptr;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)lds, 16, voffset, 0, 0, 0);
+    }
 }
 
 // ONE: 1x1 filter, no padding (a plain GEMM over gathered rows): no tap arithmetic in the loop.
@@ -61,16 +73,32 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* 
 //          is the busiest unit of this kernel (PMC: SQ_ACTIVE_INST_LDS 71 % on a 768-deep GEMM).  The lane ->
 //          LDS slot map of the DMA is linear, so each lane fetches the chunk that belongs in its slot
 //          (the XOR swizzle moves to the source address); padding / tile edges still read zeros by range check.
+constexpr int dma_depth(int stg) { return stg == 3 ? 2 : stg == 4 ? 4 : stg == 5 ? 6 : 1; }
+constexpr int igemm_lds_bytes(int wp, int wc, int stg) {
+    const int stage = (wp + wc) * 64 * BK * 2, epi = wp * 64 * (wc * 64 + 8) * 2;
+    const int ring = (stg >= 3 ? dma_depth(stg) + 1 : 2) * stage;
+    return ring > epi ? ring : epi;
+}
+constexpr int igemm_waves_per_simd(int wp, bool one, int stg) {     // __launch_bounds__ occupancy target
+    return stg == 1 ? ((wp == 4 && !one) ? 2 : 3) : stg == 3 ? 3 : stg >= 4 ? 2 : 4;
+}
+
 template <int WP, int WC, int MODE, bool ONE, int STG>
-__global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) void conv_igemm_kernel(ConvArgs a, int tiles_c, long M_all, int Kg_all) {
+__global__ __launch_bounds__(256, igemm_waves_per_simd(WP, ONE, STG)) void conv_igemm_kernel(ConvArgs a, int tiles_c, long M_all, int Kg_all) {
     constexpr int BP = WP * 64, BC = WC * 64;
     constexpr int XR = BP * CHUNKS / 256;  // x rows per thread
     constexpr int WR = BC * CHUNKS / 256;  // w rows per thread
     constexpr int CS = BC + 8;             // epilogue row stride (elements)
     constexpr int STAGE_BYTES = (BP + BC) * BK * 2;
     constexpr int EPI_BYTES = BP * CS * 2;
-    constexpr int LDS_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    constexpr int DEPTH = dma_depth(STG);  // tiles in flight ahead of the one being multiplied (counted DMA variants)
+    constexpr int NSTAGE = STG >= 3 ? DEPTH + 1 : 2;
+    constexpr int LDS_BYTES = igemm_lds_bytes(WP, WC, STG);
+    static_assert(LDS_BYTES >= NSTAGE * STAGE_BYTES && LDS_BYTES >= EPI_BYTES, "LDS plan");
+    constexpr bool DYN_LDS = LDS_BYTES > 65536;   // above the static limit the launch passes the size
+    __shared__ __attribute__((aligned(16))) unsigned char smem_static[DYN_LDS ? 16 : LDS_BYTES];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dynamic[];
+    unsigned char* const smem = DYN_LDS ? smem_dynamic : smem_static;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave / WC, wc = wave % WC;
@@ -113,6 +141,9 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
     const unsigned wbytes = (unsigned)a.K * KgW * 2u;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, wbytes, 0x00020000);
+    const unsigned long long xaddr = (unsigned long long)a.x, waddr = (unsigned long long)a.w;
+    const u32x4 xrs4 = {(unsigned)xaddr, (unsigned)(xaddr >> 32), xbytes, 0x00020000u};   // the same descriptors as plain words
+    const u32x4 wrs4 = {(unsigned)waddr, (unsigned)(waddr >> 32), wbytes, 0x00020000u};
 
     // ---- per-thread gather state ----
     const int chunk = tid & 3;
@@ -152,7 +183,7 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
     const int wsw = chunk ^ swz4(lrow);  // (row>>2)&3 is the same for lrow + 64*i
     constexpr bool RING = STG == 1;
     // register staging: load chunk `chunk`, store it to slot `wsw`;  DMA: slot = lane order = `chunk`, so load chunk `wsw`
-    int kr = 0, ks = 0, kc = (STG == 2 ? wsw : chunk) * 8;  // (tap row, tap col, channel) of this thread's chunk
+    int kr = 0, ks = 0, kc = (STG >= 2 ? wsw : chunk) * 8;  // (tap row, tap col, channel) of this thread's chunk
     if (!ONE) while (kc >= a.C) { kc -= a.C; if (++ks == ns) { ks = 0; ++kr; } }
 
     // Two register sets form a ring: the loads of tile t+2 are issued before the MFMAs of tile
@@ -206,9 +237,9 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
         if (ONE) {                                                                               \
             const unsigned kadd = kc < Kg ? (unsigned)kc * 2u : xbytes;                          \
             _Pragma("unroll") for (int i = 0; i < XR; ++i)                                       \
-                dma16(xrs, xs_ + i * (64 * BK * 2), xb[i] + kadd); \
+                dma16<(STG >= 3)>(xrs, xrs4, xs_ + i * (64 * BK * 2), xb[i] + kadd); \
             _Pragma("unroll") for (int i = 0; i < WR; ++i)                                       \
-                dma16(wrs, ws_ + i * (64 * BK * 2), wb[i] + (unsigned)kc * 2u); \
+                dma16<(STG >= 3)>(wrs, wrs4, ws_ + i * (64 * BK * 2), wb[i] + (unsigned)kc * 2u); \
             kc += BK;                                                                            \
         } else {                                                                                 \
             const bool kok = kr < nr;                                                            \
@@ -218,11 +249,11 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
                 else           { hi = hi0[i] - kr; wi = wi0[i] - ks; }                           \
                 const bool ok = kok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W; \
                 const unsigned off = ((xb[i] + (unsigned)(hi * a.W + wi)) * (unsigned)a.C + (unsigned)kc) * 2u; \
-                dma16(xrs, xs_ + i * (64 * BK * 2), ok ? off : xbytes); \
+                dma16<(STG >= 3)>(xrs, xrs4, xs_ + i * (64 * BK * 2), ok ? off : xbytes); \
             }                                                                                    \
             const unsigned wk = (unsigned)(((r0 + tstep * kr) * a.S + (s0 + tstep * ks)) * a.C + kc) * 2u; \
             _Pragma("unroll") for (int i = 0; i < WR; ++i)                                       \
-                dma16(wrs, ws_ + i * (64 * BK * 2), kok ? wb[i] + wk : wbytes); \
+                dma16<(STG >= 3)>(wrs, wrs4, ws_ + i * (64 * BK * 2), kok ? wb[i] + wk : wbytes); \
             kc += BK;                                                                            \
             while (kc >= a.C) { kc -= a.C; if (++ks == ns) { ks = 0; ++kr; } }                   \
         }                                                                                        \
@@ -254,7 +285,33 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
 
     // Loads past the last K tile fall outside the buffers (zeros) and their LDS image is never
     // read, so the loop body carries no conditions.
-    if (STG == 2) {
+    if (STG >= 3) {
+        // DMA `DEPTH` tiles ahead over DEPTH + 1 LDS buffers: when tile kt is multiplied, tiles kt+1 .. kt+DEPTH-1
+        // have had whole iterations to land and tile kt+DEPTH is being issued; the wait before the barrier
+        // leaves the DEPTH-1 newest tiles' loads outstanding (vmcnt counts DMA loads in issue order).  The
+        // depth is picked by the host from the number of workgroups per CU: few resident workgroups cannot hide
+        // the ~1 us load latency by occupancy, but then have the LDS for a deep ring.
+        constexpr int LPT = XR + WR;                                       // loads per tile per lane
+        constexpr int OUTSTANDING = (DEPTH - 1) * LPT;
+        static_assert(OUTSTANDING < 64, "vmcnt is a 6-bit counter");
+        constexpr int WAIT_OLDEST_TILE = (OUTSTANDING & 15) | ((OUTSTANDING >> 4) << 14) | (7 << 4) | (15 << 8);   // vmcnt only
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) DPA_DMA_TILE(d)
+        __builtin_amdgcn_s_waitcnt(WAIT_OLDEST_TILE);
+        __syncthreads();
+        int cur = 0, nxt = DEPTH;
+        for (int kt = 0; kt < nk; ++kt) {
+            DPA_DMA_TILE(nxt)                  // tile kt + DEPTH (its buffer was last read in iteration kt - 1)
+            __builtin_amdgcn_sched_barrier(0);
+            DPA_COMPUTE(cur)
+            __builtin_amdgcn_s_waitcnt(WAIT_OLDEST_TILE);
+            __syncthreads();
+            cur = cur == DEPTH ? 0 : cur + 1;
+            nxt = nxt == DEPTH ? 0 : nxt + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail tiles' (zero) DMA must land before LDS is reused
+        __syncthreads();
+    } else if (STG == 2) {
         // tile kt+1 is DMA-ed into the other buffer while tile kt is multiplied; the DMA counts on vmcnt
         DPA_DMA_TILE(0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -301,11 +358,51 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
         }
     }
 
+    // ---- epilogue: bias/activation, stage the bf16 tile in LDS ----
+    unsigned short* cs = (unsigned short*)smem;
+    const int q4 = (lane >> 4) * 4;
+    if (a.bias == nullptr && a.act == 0) {          // every BatchNorm-ed conv and every dgrad: pack and go
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint2 pk;
+                pk.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+                pk.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+                *(uint2*)(cs + (wp * 64 + j * 16 + frow) * CS + wc * 64 + i * 16 + q4) = pk;
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int col = wc * 64 + i * 16 + q4;  // channel inside the block tile (4 consecutive)
+            float b[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[r] = a.bias[min(c0 + col + r, a.K - 1)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pix = wp * 64 + j * 16 + frow;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[i][j][r] + b[r];
+                    if (a.act == 1) t = fmaxf(t, 0.f);
+                    else if (a.act == 2) t = gelu_tanh(t);
+                    v[r] = t;
+                }
+                uint2 pk;
+                pk.x = pack_bf16x2(v[0], v[1]);
+                pk.y = pack_bf16x2(v[2], v[3]);
+                *(uint2*)(cs + pix * CS + col) = pk;
+            }
+        }
+    }
     // ---- write-out geometry, and an early issue of everything the write-out READS from memory
-    //      (residual / gradient operand and its bit mask).  Issued here, the loads are in flight
-    //      while the accumulators are staged and the statistics run; issued inside the write-out
-    //      loop, each of the 8 passes paid a full memory round trip (measured: the fused epilogues
-    //      streamed at < 4 TB/s where the stand-alone BatchNorm kernels reach 5). ----
+    //      (residual / gradient operand and its bit mask).  Issued here - the accumulators are in
+    //      LDS, their registers free - the loads fly across the barrier and the statistics; issued
+    //      inside the write-out loop, each of the 8 passes paid a full memory round trip (measured:
+    //      the fused epilogues streamed at < 4 TB/s where the stand-alone BatchNorm kernels reach 5). ----
     constexpr int CPR = BC / 8;        // chunks per row
     constexpr int RPP = 256 / CPR;     // rows per pass
     constexpr int NPASS = BP / RPP;
@@ -350,46 +447,6 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
         for (int pss = 0; pss < NPASS; ++pss) { pre[pss] = u32x4{0u, 0u, 0u, 0u}; pmk[pss] = 0u; }
     }
 
-    // ---- epilogue: bias/activation, stage the bf16 tile in LDS ----
-    unsigned short* cs = (unsigned short*)smem;
-    const int q4 = (lane >> 4) * 4;
-    if (a.bias == nullptr && a.act == 0) {          // every BatchNorm-ed conv and every dgrad: pack and go
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint2 pk;
-                pk.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
-                pk.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
-                *(uint2*)(cs + (wp * 64 + j * 16 + frow) * CS + wc * 64 + i * 16 + q4) = pk;
-            }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int col = wc * 64 + i * 16 + q4;  // channel inside the block tile (4 consecutive)
-            float b[4] = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias != nullptr) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) b[r] = a.bias[min(c0 + col + r, a.K - 1)];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int pix = wp * 64 + j * 16 + frow;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = acc[i][j][r] + b[r];
-                    if (a.act == 1) t = fmaxf(t, 0.f);
-                    else if (a.act == 2) t = gelu_tanh(t);
-                    v[r] = t;
-                }
-                uint2 pk;
-                pk.x = pack_bf16x2(v[0], v[1]);
-                pk.y = pack_bf16x2(v[2], v[3]);
-                *(uint2*)(cs + pix * CS + col) = pk;
-            }
-        }
-    }
     __syncthreads();
 
     // ---- optional BatchNorm statistics of the bf16-rounded tile, on the matrix cores: for a block
@@ -533,6 +590,23 @@ __global__ __launch_bounds__(256, STG == 1 ? ((WP == 4 && !ONE) ? 2 : 3) : 4) vo
 #undef DPA_STORE_TILE
 #undef DPA_COMPUTE
 
+// Dynamic LDS of an instantiation (0 when the static array is used); above 64 KiB the kernel must be
+// allowed the size once per process.
+template <typename KernelT>
+size_t dynamic_lds(KernelT kernel, int bytes) {
+    if (bytes <= 65536) return 0;
+    static bool allowed = false;        // one flag per KernelT instantiation = per kernel
+    if (!allowed) {
+        const hipError_t err = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (err != hipSuccess) {
+            fprintf(stderr, "conv_igemm: cannot allow %d bytes of LDS: %s\n", bytes, hipGetErrorString(err));
+            abort();
+        }
+        allowed = true;
+    }
+    return (size_t)bytes;
+}
+
 template <int WP, int WC, int STG>
 void launch_by_parity(const ConvArgs& a, hipStream_t st) {      // strided dgrad: one grid row per pixel parity class
     const long M = (long)a.N * a.Ho * a.Wo;
@@ -541,7 +615,9 @@ void launch_by_parity(const ConvArgs& a, hipStream_t st) {      // strided dgrad
     const int st_ = a.stride;
     const long mc = (long)a.N * ((a.Ho + st_ - 1) / st_) * ((a.Wo + st_ - 1) / st_);   // largest parity class
     const int tiles_p = (int)((mc + WP * 64 - 1) / (WP * 64));
-    hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 2, false, STG>), dim3(tiles_p * tiles_c, st_ * st_), dim3(256), 0, st, a, tiles_c, M, Kg);
+    auto kernel = conv_igemm_kernel<WP, WC, 2, false, STG>;
+    const size_t lds = dynamic_lds(kernel, igemm_lds_bytes(WP, WC, STG));
+    hipLaunchKernelGGL(kernel, dim3(tiles_p * tiles_c, st_ * st_), dim3(256), lds, st, a, tiles_c, M, Kg);
 }
 
 template <int WP, int WC, bool ONE, int STG>
@@ -551,40 +627,51 @@ void launch(const ConvArgs& a, hipStream_t st) {
     const int Kg = a.R * a.S * a.C;
     const int tiles_c = (a.K + WC * 64 - 1) / (WC * 64);
     const int tiles_p = (int)((M + WP * 64 - 1) / (WP * 64));
-    if (a.mode == 0)
-        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 0, ONE, STG>), dim3(tiles_p * tiles_c), dim3(256), 0, st, a, tiles_c, M, Kg);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<WP, WC, 1, ONE, STG>), dim3(tiles_p * tiles_c), dim3(256), 0, st, a, tiles_c, M, Kg);
+    if (a.mode == 0) {
+        auto kernel = conv_igemm_kernel<WP, WC, 0, ONE, STG>;
+        const size_t lds = dynamic_lds(kernel, igemm_lds_bytes(WP, WC, STG));
+        hipLaunchKernelGGL(kernel, dim3(tiles_p * tiles_c), dim3(256), lds, st, a, tiles_c, M, Kg);
+    } else {
+        auto kernel = conv_igemm_kernel<WP, WC, 1, ONE, STG>;
+        const size_t lds = dynamic_lds(kernel, igemm_lds_bytes(WP, WC, STG));
+        hipLaunchKernelGGL(kernel, dim3(tiles_p * tiles_c), dim3(256), lds, st, a, tiles_c, M, Kg);
+    }
 }
 
 }  // namespace
 
 int conv_stats_rows(long M) { (void)M; return 32; }
 
-// DPA_IGEMM_STG=0/1/2 forces a staging variant (experiments).
-static int staging(const ConvArgs& a) {
+// Staging variant of a launch.  DPA_IGEMM_STG=0..3 forces one (experiments; 4 and 5 = DMA depth 4 / 6 exist in
+// the template but are not instantiated: measured slower than depth 2 on every shape, few-workgroup GEMMs included).
+// Measured per ResNet-50 layer and on the GPT-2 GEMMs (scripts/bench_conv.py, bench_gemm.py under each value):
+// sum over the network's fprop + dgrad 7.95 ms LDS-DMA (2) / 8.07 counted DMA (3) / 8.43 register ring (1) /
+// 8.56 single register set (0).  The counted depth-2 DMA wins where a CU holds only 1-3 workgroups (layer-4 3x3:
+// 68.7 vs 78.3 us; the 8192-token GPT-2 GEMMs: +5-9 %), the 4-resident-workgroup plain DMA everywhere else.
+static int staging(const ConvArgs& a, bool one) {
     static const int forced = [] { const char* e = getenv("DPA_IGEMM_STG"); return e ? atoi(e) : -1; }();
-    if (forced >= 0) return forced;
+    if (forced >= 0) return forced > 3 ? 3 : forced;
     const long M = (long)a.N * a.Ho * a.Wo;
     const bool wide = a.K <= 64;
     const long bp = wide ? 256 : 128, bc = wide ? 64 : 128;
     long blocks = ((M + bp - 1) / bp) * ((a.K + bc - 1) / bc);
     if (a.mode != 0 && a.stride > 1) blocks /= (a.stride * a.stride);   // per parity class
-    // Measured on the ResNet-50 shapes (scripts/bench_conv.py, DPA_IGEMM_RING=0/1): grids of many short
-    // workgroups (layer-1 sized, >= ~16 per CU) gain 5-10 % from the 4th resident wave, long-K grids with
-    // few workgroups per CU lose up to 15 % without the deeper prefetch.
-    return blocks < 4096 ? 1 : 0;
+    const long depth = (long)a.R * a.S * a.C;
+    if (blocks <= 512) return 3;
+    if (one && depth >= 768 && blocks <= 2048) return 3;
+    return 2;
 }
 
 void conv_igemm(const ConvArgs& a, hipStream_t st) {
     // 1x1 / no padding: plain GEMM gather (strided fprop included; strided dgrad goes by parity class)
     const bool one = a.R == 1 && a.S == 1 && a.pad == 0 && (a.mode == 0 || a.stride == 1);
-    const int stg = staging(a);
+    const int stg = staging(a, one);
 #define DPA_DISPATCH(WP_, WC_, ONE_)                                         \
     switch (stg) {                                                           \
         case 0: launch<WP_, WC_, ONE_, 0>(a, st); break;                     \
         case 1: launch<WP_, WC_, ONE_, 1>(a, st); break;                     \
-        default: launch<WP_, WC_, ONE_, 2>(a, st); break;                    \
+        case 2: launch<WP_, WC_, ONE_, 2>(a, st); break;                     \
+        default: launch<WP_, WC_, ONE_, 3>(a, st); break;                    \
     }
     if (a.K <= 64) { if (one) DPA_DISPATCH(4, 1, true) else DPA_DISPATCH(4, 1, false) }
     else           { if (one) DPA_DISPATCH(2, 2, true) else DPA_DISPATCH(2, 2, false) }
