@@ -73,6 +73,34 @@ __device__ __forceinline__ float gelu_tanh_grad(float x) {
     return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
 }
 
+// 16 B per lane from a buffer descriptor straight into LDS (lane-linear destination from the wave-uniform `lds`).
+// COUNTED = false: the compiler's builtin; it then treats every later LDS read as dependent on the DMA and
+// drains vmcnt to 0 before each barrier.  COUNTED = true: the same instruction issued from inline assembly, which
+// leaves the vmcnt bookkeeping to the kernel (counted waits, two tiles in flight).  Loads complete in issue
+// order, so compiler-inserted waits for its own loads only ever become stricter by the ones it cannot see.
+template <bool COUNTED>
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, u32x4 rs4, unsigned char* lds, unsigned voffset) {
+    if (COUNTED) {
+        typedef __attribute__((address_space(3))) unsigned char* lds_byte_ptr;
+        const unsigned lds_addr = (unsigned)(unsigned long long)(lds_byte_ptr)lds;
+        asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                     :: "v"(voffset), "s"(rs4), "s"(lds_addr) : "memory", "m0");
+    } else {
+        typedef __attribute__((address_space(3))) void* lds_void_ptr;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)lds, 16, voffset, 0, 0, 0);
+    }
+}
+
+// Descriptor words of a raw buffer (what __builtin_amdgcn_make_buffer_rsrc(ptr, 0, bytes, 0x00020000) holds), for
+// the inline-assembly loads.
+__device__ __forceinline__ u32x4 buffer_words(const void* ptr, unsigned bytes) {
+    const unsigned long long p = (unsigned long long)ptr;
+    return u32x4{(unsigned)p, (unsigned)(p >> 32), bytes, 0x00020000u};
+}
+
+// s_waitcnt immediate that waits for vmcnt <= n only (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14])
+constexpr int waitcnt_vm_only(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace dpa

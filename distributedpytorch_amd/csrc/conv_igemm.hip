@@ -43,24 +43,6 @@ __device__ __forceinline__ int swz4(int row) {  // conflict-free chunk swizzle f
     return (0x78 >> (2 * ((row >> 2) & 3))) & 3;  // {0,2,3,1}[(row>>2)&3]
 }
 
-// 16 B per lane from a buffer descriptor straight into LDS (lane-linear destination from the wave-uniform `lds`).
-// COUNTED = false: the compiler's builtin; it then treats every later LDS read as dependent on the DMA and
-// drains vmcnt to 0 before each barrier.  COUNTED = true: the same instruction issued from inline assembly, which
-// leaves the vmcnt bookkeeping to the kernel (counted waits, two tiles in flight).  Loads complete in issue
-// order, so compiler-inserted waits for its own loads only ever become stricter by the ones it cannot see.
-template <bool COUNTED>
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, u32x4 rs4, unsigned char* lds, unsigned voffset) {
-    if (COUNTED) {
-        typedef __attribute__((address_space(3))) unsigned char* lds_byte_ptr;
-        const unsigned lds_addr = (unsigned)(unsigned long long)(lds_byte_ptr)lds;
-        asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
-                     :: "v"(voffset), "s"(rs4), "s"(lds_addr) : "memory", "m0");
-    } else {
-        typedef __attribute__((address_space(3))) void* lds_void_ptr;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)lds, 16, voffset, 0, 0, 0);
-    }
-}
-
 // ONE: 1x1 filter, no padding (a plain GEMM over gathered rows): no tap arithmetic in the loop.
 // Two pipelining variants.  RING: two register sets, loads two tiles ahead, 3 waves per SIMD (<= 168
 // VGPRs; the 256x64 general-gather variant runs at 2).  !RING: one register set (write tile t+1 right

@@ -16,8 +16,11 @@
 // the fp32 gradient with global_atomic_add_f32 (gradients stay fp32 end to end).
 //
 // Block = 4 waves as 2x2 (128 out-channels x 128 filter columns) or 1x4
-// (64 x 256, for 64-channel layers); 32 pixels per K step; register-staged double
-// buffering with one barrier per step.
+// (64 x 256, for 64-channel layers); 32 pixels per K step; one barrier per step.  Two staging
+// variants: DMA (default) - both operands go global -> LDS with `buffer_load ... lds`, two tiles in
+// flight over three LDS buffers under a counted vmcnt, the XOR swizzle applied on the source side;
+// and the register ring it replaced (three register sets, ds_write_b128), kept selectable
+// (DPA_WGRAD_DMA=0) as the measured baseline.
 #include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
@@ -42,8 +45,8 @@ __device__ __forceinline__ short4v tr_read(const unsigned char* p) {
 
 // LIN: 1x1 filter, stride 1, no padding (and every Linear layer): the x operand is a plain
 // [pixel][channel] matrix like dy, so neither gather needs pixel arithmetic.
-template <int WM, int WN, bool LIN>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a, int tiles_n, int tiles, long P, int Kg, int steps_per_split) {
+template <int WM, int WN, bool LIN, bool DMA>
+__global__ __launch_bounds__(256, DMA ? 3 : 2) void conv_wgrad_kernel(WgradArgs a, int tiles_n, int tiles, long P, int Kg, int steps_per_split) {
     constexpr int BM = WM * 64;           // out-channel rows of dw per block
     constexpr int BN = WN * 64;           // filter columns (r,s,c) per block
     constexpr int A_CPR = BM / 8;         // 16-B chunks per dy tile row
@@ -89,18 +92,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a, int til
     // ---- A (dy) loads: thread -> (pixel row, channel chunk); the offset advances by a constant ----
     const int a_ch = tid % A_CPR, a_row0 = tid / A_CPR;
     constexpr int A_RSTEP = 256 / A_CPR;
+    // DMA writes LDS in lane order, so the lane that owns slot `a_ch` of a row fetches the chunk the swizzle
+    // puts there (the XOR key is the same for all of a thread's rows: they are A_RSTEP = 16 or 32 apart)
+    const int a_src = DMA ? ((((a_ch >> 2) ^ swz_key<BM * 2>(a_row0)) << 2) | (a_ch & 3)) : a_ch;
     unsigned a_off[A_LD];
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-        a_off[i] = ((unsigned)(p_begin + a_row0 + i * A_RSTEP) * (unsigned)a.K + (unsigned)(k0 + a_ch * 8)) * 2u;
-        if (k0 + a_ch * 8 >= a.K) a_off[i] |= OOB;
+        a_off[i] = ((unsigned)(p_begin + a_row0 + i * A_RSTEP) * (unsigned)a.K + (unsigned)(k0 + a_src * 8)) * 2u;
+        if (k0 + a_src * 8 >= a.K) a_off[i] |= OOB;
     }
     const unsigned a_step = (unsigned)BKP * (unsigned)a.K * 2u;
 
     // ---- B (x gather) loads: thread's filter column is fixed for the whole loop ----
     const int b_ch = tid % B_CPR, b_row0 = tid / B_CPR;
     constexpr int B_RSTEP = 256 / B_CPR;
-    const int col = n0 + b_ch * 8;
+    const int b_src = DMA ? ((((b_ch >> 2) ^ swz_key<BN * 2>(b_row0)) << 2) | (b_ch & 3)) : b_ch;
+    const int col = n0 + b_src * 8;
     const bool b_cok = col < Kg;
     unsigned b_off[B_LD];                 // LIN: running byte offset
     int pn[B_LD], pho[B_LD], pwo[B_LD];   // general: pixel state (n, ho, wo) of each row
@@ -151,6 +158,36 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a, int til
                 const bool ok = prem[i] > 0 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W; \
                 const unsigned off = ((unsigned)((pn[i] * a.H + hi) * a.W + wi) * (unsigned)a.C + (unsigned)fc) * 2u; \
                 BREG[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? off : OOB, 0, 0);      \
+                prem[i] -= BKP;                                                                  \
+                pwo[i] += r32; pho[i] += q32;                                                    \
+                if (pwo[i] >= a.Wo) { pwo[i] -= a.Wo; ++pho[i]; }                                \
+                while (pho[i] >= a.Ho) { pho[i] -= a.Ho; ++pn[i]; }                              \
+            }                                                                                    \
+        }                                                                                        \
+    }
+
+    // The same gather as DPA_WG_LOAD, landing in LDS buffer BUF: per instruction a wave fills 1 KiB
+    // (lane l -> +16 l), which is rows 4w..4w+3 (256-byte rows) of the i-th 4 KiB slab of the operand.
+    const u32x4 dyrs4 = buffer_words(a.dy, dybytes), xrs4 = buffer_words(a.x, xbytes);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#define DPA_WG_DMA(BUF)                                                                          \
+    {                                                                                            \
+        unsigned char* as_ = smem + (BUF) * STAGE + wave_u * 1024;                               \
+        unsigned char* bs_ = as_ + A_BYTES;                                                      \
+        _Pragma("unroll") for (int i = 0; i < A_LD; ++i) {                                       \
+            dma16<true>(dyrs, dyrs4, as_ + i * 4096, a_off[i]);                                  \
+            a_off[i] += a_step;                                                                  \
+        }                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < B_LD; ++i) {                                       \
+            if (LIN) {                                                                           \
+                dma16<true>(xrs, xrs4, bs_ + i * 4096, b_off[i]);                                \
+                b_off[i] += b_step;                                                              \
+            } else {                                                                             \
+                const int hi = pho[i] * a.stride - a.pad + fr;                                   \
+                const int wi = pwo[i] * a.stride - a.pad + fs;                                   \
+                const bool ok = prem[i] > 0 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W; \
+                const unsigned off = ((unsigned)((pn[i] * a.H + hi) * a.W + wi) * (unsigned)a.C + (unsigned)fc) * 2u; \
+                dma16<true>(xrs, xrs4, bs_ + i * 4096, ok ? off : OOB);                          \
                 prem[i] -= BKP;                                                                  \
                 pwo[i] += r32; pho[i] += q32;                                                    \
                 if (pwo[i] >= a.Wo) { pwo[i] -= a.Wo; ++pho[i]; }                                \
@@ -221,6 +258,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a, int til
     }
 
     // tiles past the block's range load zeros (never consumed), so the loop carries no conditions
+    if (DMA) {
+        constexpr int LPT = A_LD + B_LD;                       // DMA instructions per tile per lane
+        DPA_WG_DMA(0)
+        DPA_WG_DMA(1)
+        __builtin_amdgcn_s_waitcnt(waitcnt_vm_only(LPT));      // tile 0 has landed, tile 1 may still fly
+        __syncthreads();
+        int cur = 0, nxt = 2;
+        for (int t = 0; t < nsteps; ++t) {
+            DPA_WG_DMA(nxt)                                    // tile t + 2 (its buffer was last read in step t - 1)
+            __builtin_amdgcn_sched_barrier(0);
+            DPA_WG_COMPUTE(cur)
+            __builtin_amdgcn_s_waitcnt(waitcnt_vm_only(LPT));  // tile t + 1 has landed
+            __syncthreads();
+            cur = cur == 2 ? 0 : cur + 1;
+            nxt = nxt == 2 ? 0 : nxt + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
     DPA_WG_LOAD(ar0, br0)
     DPA_WG_LOAD(ar1, br1)
     DPA_WG_LOAD(ar2, br2)
@@ -252,6 +307,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a, int til
             DPA_WG_COMPUTE(1)
         }
     }
+    }
 
     // ---- accumulate into fp32 dw: each register = 2 rows x 32 contiguous columns ----
     const int ccol = lane & 31, rhalf = (lane >> 5) * 4;
@@ -269,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a, int til
 }
 
 #undef DPA_WG_LOAD
+#undef DPA_WG_DMA
 #undef DPA_WG_STORE
 #undef DPA_WG_COMPUTE
 
@@ -280,7 +337,7 @@ int wgrad_target_blocks() {
     return v;
 }
 
-template <int WM, int WN, bool LIN>
+template <int WM, int WN, bool LIN, bool DMA>
 void launch(const WgradArgs& a, hipStream_t st) {
     const long P = (long)a.N * a.Ho * a.Wo;
     const int Kg = a.R * a.S * a.C;
@@ -298,15 +355,24 @@ void launch(const WgradArgs& a, hipStream_t st) {
     const int sps = (steps + split - 1) / split;
     split = (steps + sps - 1) / sps;
     dim3 grid(tiles * split), block(256);
-    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, LIN>), grid, block, 0, st, a, tiles_n, tiles, P, Kg, sps);
+    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, LIN, DMA>), grid, block, 0, st, a, tiles_n, tiles, P, Kg, sps);
 }
 
 }  // namespace
 
 void conv_wgrad(const WgradArgs& a, hipStream_t st) {
+    // DPA_WGRAD_DMA=0/1 forces a staging variant.  Measured over the ResNet-50 layers (scripts/bench_conv.py):
+    // DMA -8..-13 % on every 3x3 and on the 1x1 layers of stages 3-4, +4..+11 % on the 1x1 layers of stages 1-2,
+    // which stream > 200k pixels against tiny filters (HBM-bound; the ring's three tiles in flight matter there).
+    static const int forced = [] { const char* e = getenv("DPA_WGRAD_DMA"); return e ? atoi(e) : -1; }();
     const bool lin = a.R == 1 && a.S == 1 && a.pad == 0 && a.stride == 1;
-    if (a.K <= 64) { if (lin) launch<1, 4, true>(a, st); else launch<1, 4, false>(a, st); }
-    else           { if (lin) launch<2, 2, true>(a, st); else launch<2, 2, false>(a, st); }
+    const bool dma = forced >= 0 ? forced != 0 : !(lin && (long)a.N * a.Ho * a.Wo >= 150000);
+#define DPA_WG_DISPATCH(WM_, WN_)                                                                \
+    if (dma) { if (lin) launch<WM_, WN_, true, true>(a, st); else launch<WM_, WN_, false, true>(a, st); }  \
+    else     { if (lin) launch<WM_, WN_, true, false>(a, st); else launch<WM_, WN_, false, false>(a, st); }
+    if (a.K <= 64) { DPA_WG_DISPATCH(1, 4) }
+    else           { DPA_WG_DISPATCH(2, 2) }
+#undef DPA_WG_DISPATCH
 }
 
 }  // namespace dpa
