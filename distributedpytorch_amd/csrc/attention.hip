@@ -82,6 +82,10 @@ __device__ __forceinline__ bf16x8 pack_regs(const floatx16& x, int s) {   // reg
     return r;
 }
 
+// 2^x as ONE v_exp_f32: arguments here are <= 0 (score minus running max / log-sum-exp), so exp2f's denormal
+// and overflow range handling (5 extra VALU instructions per element) buys nothing; very negative -> 0.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 __device__ __forceinline__ void zero16(floatx16& a) {
@@ -104,7 +108,7 @@ __device__ __forceinline__ void store_T(unsigned short* __restrict__ dst, const 
 }
 
 // ------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
                                                        float* __restrict__ lse, int T, int H, float c_log2) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
     unsigned char* Ks = smem;
@@ -149,24 +153,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const unsigned short* __r
         }
         const bool diag = (j * TILE + TILE - 1) > qw0;             // tile may contain keys > some query of the wave
         float mx = NEG_BIG;
+        if (diag) {                                              // wave-uniform: only these tiles pay for the mask
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
+            for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s = S[t2][r] * c_log2;
-                if (diag && (j * TILE + 32 * t2 + acc_row(r, h)) > q) s = NEG_BIG;
-                S[t2][r] = s;
-                mx = fmaxf(mx, s);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    float s = S[t2][r] * c_log2;
+                    if ((j * TILE + 32 * t2 + acc_row(r, h)) > q) s = NEG_BIG;
+                    S[t2][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+        } else {
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float s = S[t2][r] * c_log2;
+                    S[t2][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mn = fmaxf(m, mx);
-        const float alpha = exp2f(m - mn);
+        const float alpha = fast_exp2(m - mn);
         float rsum = 0.f;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(S[t2][r] - mn);
+                const float p = fast_exp2(S[t2][r] - mn);
                 S[t2][r] = p;
                 rsum += p;
             }
@@ -215,7 +230,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const unsigned short* _
 }
 
 // ------------------------------------------------------------------------------ dK / dV (key-stationary)
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ d_o,
+__global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ d_o,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           unsigned short* __restrict__ dqkv, int T, int H, float scale) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES + 2 * TILE * 4];
@@ -259,6 +274,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const unsigned short* 
         if (jq * TILE + TILE - 1 < kw0) continue;                 // wave-uniform: all queries are before the wave's keys
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
+            const int qt0 = jq * TILE + 32 * t2;                  // first query of this 32-row half tile
+            if (qt0 + 31 < kw0) continue;                         // wave-uniform: still entirely before the wave's keys
             floatx16 S, dP;
             zero16(S); zero16(dP);
 #pragma unroll
@@ -267,13 +284,22 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const unsigned short* 
                 dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Os, 32 * t2 + kl, kk, h), vf[kk], dP, 0, 0, 0);
             }
             // rows = queries (registers), column = this lane's key
+            if (qt0 < kw0 + 31) {                                 // diagonal half tile: causal mask
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qr = 32 * t2 + acc_row(r, h);
-                const int qg = jq * TILE + qr;
-                const float p = (qg >= key) ? exp2f(S[r] * c_log2 - lse_s[qr]) : 0.f;
-                S[r] = p;
-                dP[r] = p * (dP[r] - del_s[qr]) * scale;
+                for (int r = 0; r < 16; ++r) {
+                    const int qr = 32 * t2 + acc_row(r, h);
+                    const float p = (jq * TILE + qr >= key) ? fast_exp2(S[r] * c_log2 - lse_s[qr]) : 0.f;
+                    S[r] = p;
+                    dP[r] = p * (dP[r] - del_s[qr]) * scale;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qr = 32 * t2 + acc_row(r, h);
+                    const float p = fast_exp2(S[r] * c_log2 - lse_s[qr]);
+                    S[r] = p;
+                    dP[r] = p * (dP[r] - del_s[qr]) * scale;
+                }
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -293,7 +319,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const unsigned short* 
 }
 
 // ------------------------------------------------------------------------------ dQ (query-stationary)
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ d_o,
+__global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ d_o,
                                                          const float* __restrict__ lse, const float* __restrict__ delta,
                                                          unsigned short* __restrict__ dqkv, int T, int H, float scale) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
@@ -336,6 +362,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const unsigned short* _
         if (j * TILE > qw0 + 31) continue;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
+            const int kt0 = j * TILE + 32 * t2;                   // first key of this 32-row half tile
+            if (kt0 > qw0 + 31) continue;                         // wave-uniform: entirely in the wave's future
             floatx16 St, dPt;
             zero16(St); zero16(dPt);
 #pragma unroll
@@ -343,11 +371,19 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const unsigned short* _
                 St = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, 32 * t2 + ql, kk, h), qf[kk], St, 0, 0, 0);
                 dPt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs, 32 * t2 + ql, kk, h), dof[kk], dPt, 0, 0, 0);
             }
+            if (kt0 + 31 > qw0) {                                 // diagonal half tile: causal mask
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kg = j * TILE + 32 * t2 + acc_row(r, h);
-                const float p = (kg <= q) ? exp2f(St[r] * c_log2 - lse_q) : 0.f;
-                dPt[r] = p * (dPt[r] - del_q) * scale;
+                for (int r = 0; r < 16; ++r) {
+                    const int kg = kt0 + acc_row(r, h);
+                    const float p = (kg <= q) ? fast_exp2(St[r] * c_log2 - lse_q) : 0.f;
+                    dPt[r] = p * (dPt[r] - del_q) * scale;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = fast_exp2(St[r] * c_log2 - lse_q);
+                    dPt[r] = p * (dPt[r] - del_q) * scale;
+                }
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {

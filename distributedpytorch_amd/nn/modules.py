@@ -37,7 +37,7 @@ class Conv2d(nn.Module):
 
     def forward(self, x: torch.Tensor, want_stats: bool = False, stats_buf=None):
         y, stats = ops.conv2d_nhwc(x, self.weight, self.weight_lp, self.bias, self.stride, self.padding, want_stats,
-                                   stats_buf)
+                                   stats_buf, self.weight_lp_t)
         return (y, stats) if want_stats else y
 
     def extra_repr(self):
@@ -114,9 +114,10 @@ class Linear(nn.Module):
         else:
             self.bias = None
         self.weight_lp: Optional[torch.Tensor] = None
+        self.weight_lp_t: Optional[torch.Tensor] = None    # [in, out] twin for the input gradient, kept by FlatParams
 
     def forward(self, x, keep_padding: bool = False):
-        y = ops.linear(x, self.weight, self.weight_lp, self.bias)
+        y = ops.linear(x, self.weight, self.weight_lp, self.bias, self.weight_lp_t)
         if not keep_padding and self.out_padded != self.out_features:
             y = y[..., : self.out_features]
         return y

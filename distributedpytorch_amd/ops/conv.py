@@ -32,7 +32,7 @@ def _lp(weight: torch.Tensor, weight_lp: Optional[torch.Tensor]) -> torch.Tensor
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, weight_lp, bias, stride, pad, want_stats, act, wshape, stats_buf=None):
+    def forward(ctx, x, weight, weight_lp, bias, stride, pad, want_stats, act, wshape, stats_buf=None, weight_lp_t=None):
         C = _ext.load()
         w = _lp(weight, weight_lp).view(wshape)   # KRSC view (a Linear weight [out,in] is K,1,1,C)
         outs = C.conv_fprop(x, w, bias, stride, pad, act, want_stats, stats_buf)
@@ -40,6 +40,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.weight = weight
         ctx.bias = bias
         ctx.geom = (stride, pad, act)
+        ctx.wt = weight_lp_t        # optimizer-maintained [C,R,S,K] twin (FlatParams), or None
         if want_stats:
             ctx.mark_non_differentiable(outs[1])
             return outs[0], outs[1]
@@ -54,7 +55,8 @@ class _ConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = C.conv_dgrad(dy, C.transpose_filter(w), x.shape[1], x.shape[2], stride, pad, None, None)
+            wt = ctx.wt if ctx.wt is not None else C.transpose_filter(w)
+            dx = C.conv_dgrad(dy, wt, x.shape[1], x.shape[2], stride, pad, None, None)
         weight = ctx.weight
         if weight.requires_grad:
             tgt = _sink.target(weight)
@@ -73,12 +75,12 @@ class _ConvFn(torch.autograd.Function):
             else:
                 db = torch.zeros(bias.shape, dtype=torch.float32, device=bias.device)
                 C.colsum(dy, db)
-        return dx, dw, None, db, None, None, None, None, None, None
+        return dx, dw, None, db, None, None, None, None, None, None, None
 
 
 def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, weight_lp: Optional[torch.Tensor] = None,
                 bias: Optional[torch.Tensor] = None, stride: int = 1, padding: int = 0, want_stats: bool = False,
-                stats_buf: Optional[torch.Tensor] = None):
+                stats_buf: Optional[torch.Tensor] = None, weight_lp_t: Optional[torch.Tensor] = None):
     """``x [N,H,W,C]`` * ``weight [K,R,S,C]`` -> ``y [N,Ho,Wo,K]``.
 
     Returns ``(y, stats)``; ``stats`` holds per-channel (sum, sumsq) partials of ``y``
@@ -87,19 +89,22 @@ def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, weight_lp: Optional[torch
     BatchNorm finalize kernel re-zeroes it), which avoids one allocation + memset per layer.
     """
     if _ext.use_hip(x):
-        return _ConvFn.apply(x, weight, weight_lp, bias, stride, padding, want_stats, 0, tuple(weight.shape), stats_buf)
+        return _ConvFn.apply(x, weight, weight_lp, bias, stride, padding, want_stats, 0, tuple(weight.shape), stats_buf,
+                             weight_lp_t)
     y = F.conv2d(x.permute(0, 3, 1, 2), weight.to(x.dtype).permute(0, 3, 1, 2),
                  None if bias is None else bias.to(x.dtype), stride=stride, padding=padding)
     return y.permute(0, 2, 3, 1).contiguous(), None
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, weight_lp: Optional[torch.Tensor] = None,
-           bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``y = x @ weight^T + bias`` with ``weight [out, in]``; any leading dims on ``x``."""
+           bias: Optional[torch.Tensor] = None, weight_lp_t: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``y = x @ weight^T + bias`` with ``weight [out, in]``; any leading dims on ``x``.
+    ``weight_lp_t`` is the optional bf16 ``[in, out]`` twin the input gradient multiplies by."""
     if _ext.use_hip(x):
         lead = x.shape[:-1]
         cin, cout = weight.shape[1], weight.shape[0]
         x4 = x.reshape(-1, 1, 1, cin)
-        y, _ = _ConvFn.apply(x4, weight, weight_lp, bias, 1, 0, False, 0, (cout, 1, 1, cin))
+        wt = None if weight_lp_t is None else weight_lp_t.view(cin, 1, 1, cout)
+        y, _ = _ConvFn.apply(x4, weight, weight_lp, bias, 1, 0, False, 0, (cout, 1, 1, cin), None, wt)
         return y.reshape(*lead, cout)
     return F.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))

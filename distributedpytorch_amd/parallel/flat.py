@@ -69,7 +69,8 @@ class FlatParams:
             g = self.grad[off:off + n].view(p.shape)
             p.grad = g
             self._grad_views[id(p)] = g
-        # transposed twin of the bf16 shadow for conv filters ([C,R,S,K], what dgrad consumes), refreshed by ONE
+        # transposed twin of the bf16 shadow for conv filters ([C,R,S,K]) and Linear weights ([in,out]) - what the
+        # input-gradient GEMM consumes - refreshed by ONE
         # batched kernel after every optimizer step instead of one transpose launch per layer per backward
         self.lp_t = None
         self._tr_table = None
@@ -78,11 +79,11 @@ class FlatParams:
             rows, tiles = [], 0
             for mod in module.modules():
                 w = getattr(mod, "weight", None)
-                if hasattr(mod, "weight_lp_t") and isinstance(w, nn.Parameter) and w.dim() == 4:
+                if hasattr(mod, "weight_lp_t") and isinstance(w, nn.Parameter) and w.dim() in (2, 4):
                     i = next((k for k, q in enumerate(self.params) if q is w), None)
                     if i is None:
                         continue
-                    K, R, S, C = w.shape
+                    K, R, S, C = w.shape if w.dim() == 4 else (w.shape[0], 1, 1, w.shape[1])   # Linear [out,in] = K,1,1,C
                     rows.append([offsets[i], offsets[i], K, R * S, C, tiles])
                     tiles += ((K + 31) // 32) * ((C + 31) // 32) * R * S
             if rows:
@@ -117,9 +118,12 @@ class FlatParams:
                     i = index[id(p)]
                     off = self.offsets[i]
                     setattr(mod, attr, self.lp[off:off + p.numel()].view(p.shape))
-                    if pname == "weight" and self.lp_t is not None and hasattr(mod, "weight_lp_t") and p.dim() == 4:
-                        K, R, S, C = p.shape
-                        mod.weight_lp_t = self.lp_t[off:off + p.numel()].view(C, R, S, K)
+                    if pname == "weight" and self.lp_t is not None and hasattr(mod, "weight_lp_t") and p.dim() in (2, 4):
+                        if p.dim() == 4:
+                            K, R, S, C = p.shape
+                            mod.weight_lp_t = self.lp_t[off:off + p.numel()].view(C, R, S, K)
+                        else:
+                            mod.weight_lp_t = self.lp_t[off:off + p.numel()].view(p.shape[1], p.shape[0])
 
     def refresh_lp(self) -> None:
         if self.lp is None:
