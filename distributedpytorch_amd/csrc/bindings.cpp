@@ -211,8 +211,10 @@ Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int6
     return dx;
 }
 
-// dw [K,R,S,C] fp32 += wgrad(x, dy).  dw must be initialised by the caller.
-void conv_wgrad(const Tensor& x, const Tensor& dy, Tensor& dw, int64_t stride, int64_t pad) {
+// dw [K,R,S,C] fp32 += wgrad(x, dy).  dw must be initialised by the caller.  With dbias (fp32 [K]) the bias
+// gradient dbias += column sums of dy is produced too: inside the wgrad kernel where that variant exists, else by
+// the column-sum kernels.
+void conv_wgrad(const Tensor& x, const Tensor& dy, Tensor& dw, int64_t stride, int64_t pad, const c10::optional<Tensor>& dbias) {
     CHECK_BF16(x); CHECK_BF16(dy); CHECK_F32(dw);
     TORCH_CHECK(x.dim() == 4 && dy.dim() == 4 && dw.dim() == 4, "conv_wgrad: 4-D tensors expected");
     const int64_t N = x.size(0), H = x.size(1), W = x.size(2), C = x.size(3);
@@ -227,7 +229,21 @@ void conv_wgrad(const Tensor& x, const Tensor& dy, Tensor& dw, int64_t stride, i
     dpa::WgradArgs a{};
     a.x = x.data_ptr(); a.dy = dy.data_ptr(); a.dw = dw.data_ptr<float>();
     a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = pad;
+    a.dbias = nullptr;
+    const bool want_bias = dbias.has_value() && dbias->defined();
+    if (want_bias) {
+        CHECK_F32((*dbias));
+        TORCH_CHECK(dbias->numel() == K, "conv_wgrad: dbias must have K elements");
+        if (dpa::conv_wgrad_fuses_bias(a)) a.dbias = dbias->data_ptr<float>();
+    }
     dpa::conv_wgrad(a, cur_stream());
+    if (want_bias && a.dbias == nullptr) {
+        const int64_t M = dy.numel() / K;
+        const int wr = dpa::colsum_workspace_rows(M, K);
+        Tensor ws;
+        if (wr > 0) ws = torch::empty({wr, K}, dbias->options());
+        dpa::colsum_bf16(dy.data_ptr(), dbias->data_ptr<float>(), M, K, wr > 0 ? ws.data_ptr<float>() : nullptr, cur_stream());
+    }
 }
 
 Tensor transpose_filter(const Tensor& w) {
@@ -665,7 +681,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("conv_bnb_stats", &conv_bnb_stats);
     m.def("conv_bnb_apply", &conv_bnb_apply);
     m.def("bn_bwd_coefs", &bn_bwd_coefs);
-    m.def("conv_wgrad", &conv_wgrad);
+    m.def("conv_wgrad", &conv_wgrad, py::arg("x"), py::arg("dy"), py::arg("dw"), py::arg("stride"), py::arg("pad"),
+          py::arg("dbias") = py::none());
     m.def("transpose_filter", &transpose_filter);
     m.def("transpose_filters_batched", &transpose_filters_batched);
     m.def("colsum", &colsum);

@@ -29,8 +29,10 @@ std::vector<Tensor> layernorm_fwd(const Tensor& x, const Tensor& g, const Tensor
     return {y, mean, rstd};
 }
 
-// returns (dx bf16, dgamma fp32 [C], dbeta fp32 [C])
-std::vector<Tensor> layernorm_bwd(const Tensor& dy, const Tensor& x, const Tensor& g, const Tensor& mean, const Tensor& rstd) {
+// returns (dx bf16, dgamma fp32 [C], dbeta fp32 [C]); with dgamma_acc / dbeta_acc (fp32 [C], e.g. slices of the
+// flat gradient buffer) the parameter gradients are ADDED there instead and the two returned tensors are empty
+std::vector<Tensor> layernorm_bwd(const Tensor& dy, const Tensor& x, const Tensor& g, const Tensor& mean, const Tensor& rstd,
+                                  const c10::optional<Tensor>& dgamma_acc, const c10::optional<Tensor>& dbeta_acc) {
     CHECK_BF16(dy); CHECK_BF16(x); CHECK_F32(g); CHECK_F32(mean); CHECK_F32(rstd);
     const int64_t C = x.size(-1), rows = x.numel() / C;
     TORCH_CHECK(dy.numel() == x.numel() && C % 8 == 0 && C <= 2048 && g.numel() == C && mean.numel() == rows && rstd.numel() == rows,
@@ -38,13 +40,20 @@ std::vector<Tensor> layernorm_bwd(const Tensor& dy, const Tensor& x, const Tenso
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     auto fopt = x.options().dtype(at::kFloat);
     const int pr = dpa::layernorm_partial_rows(rows);
-    Tensor dx = torch::empty_like(x), part = torch::empty({2, pr, C}, fopt), dgb = torch::empty({2, C}, fopt);
+    Tensor dx = torch::empty_like(x), part = torch::empty({2, pr, C}, fopt);
     float* pp = part.data_ptr<float>();
     dpa::layernorm_bwd(dy.data_ptr(), x.data_ptr(), g.data_ptr<float>(), mean.data_ptr<float>(), rstd.data_ptr<float>(),
                        dx.data_ptr(), pp, pp + (long)pr * C, pr, rows, C, cur_stream());
+    const bool acc = dgamma_acc.has_value() && dgamma_acc->defined() && dbeta_acc.has_value() && dbeta_acc->defined();
+    if (acc) {
+        CHECK_F32((*dgamma_acc)); CHECK_F32((*dbeta_acc));
+        TORCH_CHECK(dgamma_acc->numel() == C && dbeta_acc->numel() == C, "layernorm_bwd: accumulator shapes");
+        dpa::reduce_partials2(pp, pr, C, dgamma_acc->data_ptr<float>(), dbeta_acc->data_ptr<float>(), 1, cur_stream());
+        return {dx, Tensor(), Tensor()};
+    }
+    Tensor dgb = torch::empty({2, C}, fopt);
     float* o = dgb.data_ptr<float>();
-    dpa::reduce_partials(pp, pr, C, o, 0, cur_stream());
-    dpa::reduce_partials(pp + (long)pr * C, pr, C, o + C, 0, cur_stream());
+    dpa::reduce_partials2(pp, pr, C, o, o + C, 0, cur_stream());
     return {dx, dgb[0], dgb[1]};
 }
 

@@ -45,7 +45,9 @@ __device__ __forceinline__ short4v tr_read(const unsigned char* p) {
 
 // LIN: 1x1 filter, stride 1, no padding (and every Linear layer): the x operand is a plain
 // [pixel][channel] matrix like dy, so neither gather needs pixel arithmetic.
-template <int WM, int WN, bool LIN, bool DMA>
+// BIAS: the workgroups of the first column tile also accumulate dbias[k] = sum_p dy[p][k] - one more MFMA per
+// dy fragment against a B operand of ones, in the waves of column 0 only - instead of a separate pass over dy.
+template <int WM, int WN, bool LIN, bool DMA, bool BIAS>
 __global__ __launch_bounds__(256, DMA ? 3 : 2) void conv_wgrad_kernel(WgradArgs a, int tiles_n, int tiles, long P, int Kg, int steps_per_split) {
     constexpr int BM = WM * 64;           // out-channel rows of dw per block
     constexpr int BN = WN * 64;           // filter columns (r,s,c) per block
@@ -225,6 +227,16 @@ __global__ __launch_bounds__(256, DMA ? 3 : 2) void conv_wgrad_kernel(WgradArgs 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    floatx16 accb[2];                              // BIAS: every column of the tile holds the row's sum
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    const bool do_bias = BIAS && a.dbias != nullptr && tile_n == 0 && wn == 0;   // wave-uniform
+
     // transposed-read lane roles
     const int gi = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
     const int kofs = 8 * (gi >> 1) + tq;        // pixel row inside a 16-deep k slice (first read)
@@ -254,6 +266,10 @@ __global__ __launch_bounds__(256, DMA ? 3 : 2) void conv_wgrad_kernel(WgradArgs 
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                        \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                    \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0); \
+            if (BIAS && do_bias) {                                                               \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                    \
+                    accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, accb[i], 0, 0, 0); \
+            }                                                                                    \
         }                                                                                        \
     }
 
@@ -322,6 +338,15 @@ __global__ __launch_bounds__(256, DMA ? 3 : 2) void conv_wgrad_kernel(WgradArgs 
                 if (row < a.K && cg < Kg) atomicAdd(a.dw + (long)row * Kg + cg, acc[i][j][r]);
             }
         }
+    if (BIAS && do_bias && ccol == 0) {            // lanes 0 and 32 hold column 0: 16 rows each
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = k0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+                if (row < a.K) atomicAdd(a.dbias + row, accb[i][r]);
+            }
+    }
 }
 
 #undef DPA_WG_LOAD
@@ -337,7 +362,7 @@ int wgrad_target_blocks() {
     return v;
 }
 
-template <int WM, int WN, bool LIN, bool DMA>
+template <int WM, int WN, bool LIN, bool DMA, bool BIAS = false>
 void launch(const WgradArgs& a, hipStream_t st) {
     const long P = (long)a.N * a.Ho * a.Wo;
     const int Kg = a.R * a.S * a.C;
@@ -355,21 +380,37 @@ void launch(const WgradArgs& a, hipStream_t st) {
     const int sps = (steps + split - 1) / split;
     split = (steps + sps - 1) / sps;
     dim3 grid(tiles * split), block(256);
-    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, LIN, DMA>), grid, block, 0, st, a, tiles_n, tiles, P, Kg, sps);
+    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, LIN, DMA, BIAS>), grid, block, 0, st, a, tiles_n, tiles, P, Kg, sps);
 }
 
 }  // namespace
 
-void conv_wgrad(const WgradArgs& a, hipStream_t st) {
+namespace {
+bool use_dma(const WgradArgs& a) {
     // DPA_WGRAD_DMA=0/1 forces a staging variant.  Measured over the ResNet-50 layers (scripts/bench_conv.py):
     // DMA -8..-13 % on every 3x3 and on the 1x1 layers of stages 3-4, +4..+11 % on the 1x1 layers of stages 1-2,
     // which stream > 200k pixels against tiny filters (HBM-bound; the ring's three tiles in flight matter there).
     static const int forced = [] { const char* e = getenv("DPA_WGRAD_DMA"); return e ? atoi(e) : -1; }();
     const bool lin = a.R == 1 && a.S == 1 && a.pad == 0 && a.stride == 1;
-    const bool dma = forced >= 0 ? forced != 0 : !(lin && (long)a.N * a.Ho * a.Wo >= 150000);
+    return forced >= 0 ? forced != 0 : !(lin && (long)a.N * a.Ho * a.Wo >= 150000);
+}
+}  // namespace
+
+// the bias-gradient variant exists for the Linear-shaped DMA kernels (every GPT-2 projection)
+bool conv_wgrad_fuses_bias(const WgradArgs& a) {
+    const bool lin = a.R == 1 && a.S == 1 && a.pad == 0 && a.stride == 1;
+    return lin && use_dma(a);
+}
+
+void conv_wgrad(const WgradArgs& a, hipStream_t st) {
+    const bool lin = a.R == 1 && a.S == 1 && a.pad == 0 && a.stride == 1;
+    const bool dma = use_dma(a);
+    const bool bias = a.dbias != nullptr && conv_wgrad_fuses_bias(a);
 #define DPA_WG_DISPATCH(WM_, WN_)                                                                \
-    if (dma) { if (lin) launch<WM_, WN_, true, true>(a, st); else launch<WM_, WN_, false, true>(a, st); }  \
-    else     { if (lin) launch<WM_, WN_, true, false>(a, st); else launch<WM_, WN_, false, false>(a, st); }
+    if (dma) {                                                                                   \
+        if (lin) { if (bias) launch<WM_, WN_, true, true, true>(a, st); else launch<WM_, WN_, true, true>(a, st); } \
+        else launch<WM_, WN_, false, true>(a, st);                                               \
+    } else { if (lin) launch<WM_, WN_, true, false>(a, st); else launch<WM_, WN_, false, false>(a, st); }
     if (a.K <= 64) { DPA_WG_DISPATCH(1, 4) }
     else           { DPA_WG_DISPATCH(2, 2) }
 #undef DPA_WG_DISPATCH

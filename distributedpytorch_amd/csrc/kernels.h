@@ -53,8 +53,11 @@ struct WgradArgs {
     float* dw;        // fp32 [K, R, S, C]
     int N, H, W, C, K, R, S, Ho, Wo;
     int stride, pad;
+    float* dbias;     // optional fp32 [K]: += column sums of dy (bias gradient), computed on the MFMA beside dw
 };
 void conv_wgrad(const WgradArgs& a, hipStream_t st);
+// true when conv_wgrad's kernel for this problem also produces a.dbias (else the caller runs colsum_bf16)
+bool conv_wgrad_fuses_bias(const WgradArgs& a);
 
 // [K, RS, C] bf16 -> [C, RS, K] bf16 (filter for dgrad)
 void transpose_filter(const void* w, void* wt, int K, int RS, int C, hipStream_t st);
@@ -136,6 +139,8 @@ void layernorm_bwd(const void* dy, const void* x, const float* g, const float* m
                    void* dx, float* dg_partial, float* db_partial, int partial_rows, long rows, int C, hipStream_t st);
 int layernorm_partial_rows(long rows);
 void reduce_partials(const float* partial, int rows, int C, float* out, int accumulate, hipStream_t st);
+// partial = [2][rows][C]: both halves folded by one launch into out_a / out_b
+void reduce_partials2(const float* partial, int rows, int C, float* out_a, float* out_b, int accumulate, hipStream_t st);
 void embedding_fwd(const int64_t* tok, const void* wte, const void* wpe, void* y, long B, int T, int C, long V, hipStream_t st);
 void embedding_bwd(const int64_t* tok, const void* dy, float* dwte, float* dwpe, long B, int T, int C, long V, hipStream_t st);
 // causal flash attention, qkv packed [B, T, 3, H, D] bf16, D = 64

@@ -8,8 +8,9 @@
 namespace dpa {
 namespace {
 
-constexpr int LN_MAX_CHUNKS = 4;  // per lane -> C <= 64*8*4 = 2048
-
+// NCH = 16-byte chunks per lane (1, 2 or 4: C <= 512, 1024, 2048): the register arrays are sized by it, so the
+// common C = 768 case runs at 4+ waves/SIMD instead of the 2 a fixed 4-chunk layout allows.
+template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const unsigned short* __restrict__ x, const float* __restrict__ g,
                                                             const float* __restrict__ b, unsigned short* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd, long rows,
@@ -18,10 +19,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const unsigned short
     const int nch = C / 8;
     for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
         const unsigned short* xr = x + row * C;
-        float v[LN_MAX_CHUNKS][8];
+        float v[NCH][8];
         float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+        for (int k = 0; k < NCH; ++k) {
             const int ch = lane + k * 64;
             if (ch < nch) {
                 uint4 u = *(const uint4*)(xr + ch * 8);
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const unsigned short
         const float rs = rsqrtf(var + eps);
         if (lane == 0) { mean[row] = m; rstd[row] = rs; }
 #pragma unroll
-        for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+        for (int k = 0; k < NCH; ++k) {
             const int ch = lane + k * 64;
             if (ch < nch) {
                 float o[8];
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const unsigned short
     }
 }
 
+template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
                                                             const float* __restrict__ g, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, unsigned short* __restrict__ dx,
@@ -56,17 +58,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
                                                             long rows, int C) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = C / 8;
-    float dg[LN_MAX_CHUNKS][8], db[LN_MAX_CHUNKS][8];
+    float dg[NCH][8], db[NCH][8];
 #pragma unroll
-    for (int k = 0; k < LN_MAX_CHUNKS; ++k)
+    for (int k = 0; k < NCH; ++k)
 #pragma unroll
         for (int j = 0; j < 8; ++j) { dg[k][j] = 0.f; db[k][j] = 0.f; }
     for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
         const float m = mean[row], rs = rstd[row];
-        float xh[LN_MAX_CHUNKS][8], gy[LN_MAX_CHUNKS][8];
+        float xh[NCH][8], gy[NCH][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+        for (int k = 0; k < NCH; ++k) {
             const int ch = lane + k * 64;
             if (ch < nch) {
                 float d[8], xv[8];
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
         }
         s1 = wave_reduce_sum(s1) / (float)C; s2 = wave_reduce_sum(s2) / (float)C;
 #pragma unroll
-        for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+        for (int k = 0; k < NCH; ++k) {
             const int ch = lane + k * 64;
             if (ch < nch) {
                 float o[8];
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
     }
     // fold the 4 waves of the block through LDS, then one partial row per block
     __shared__ float red[4][64 * 8 + 8];
-    for (int pass = 0; pass < 2 * LN_MAX_CHUNKS; ++pass) {
+    for (int pass = 0; pass < 2 * NCH; ++pass) {
         const int k = pass >> 1;
         const bool is_g = (pass & 1) == 0;
         const int ch = lane + k * 64;
@@ -114,12 +116,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
     }
 }
 
-// out[c] (+)= sum_r part[r][c]: a block folds 16 columns, its 16 row groups stride the partial rows
+// out[c] (+)= sum_r part[r][c]: a block folds 16 columns, its 16 row groups stride the partial rows.
+// blockIdx.y picks one of two stacked problems (part + y * rows * C -> out_a / out_b): LayerNorm's dgamma and
+// dbeta fold in one launch.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int rows, int C,
-                                                              float* __restrict__ out, int accumulate) {
+                                                              float* __restrict__ out_a, float* __restrict__ out_b, int accumulate) {
     __shared__ float red[16][17];
     const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
+    part += (long)blockIdx.y * rows * C;
+    float* __restrict__ out = blockIdx.y == 0 ? out_a : out_b;
     float s = 0.f;
     if (c < C)
         for (int r = rg; r < rows; r += 16) s += part[(long)r * C + c];
@@ -192,7 +198,7 @@ inline int grid_for(long n) { long b = (n + 255) / 256; if (b > 4096) b = 4096; 
 
 int layernorm_partial_rows(long rows) {
     long b = (rows + 3) / 4;
-    if (b > 256) b = 256;
+    if (b > 512) b = 512;      // 2 workgroups per CU; every extra one is another partial row to fold
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -200,18 +206,26 @@ int layernorm_partial_rows(long rows) {
 void layernorm_fwd(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd,
                    long rows, int C, float eps, hipStream_t st) {
     long blocks = (rows + 3) / 4; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const unsigned short*)x, g, b,
-                       (unsigned short*)y, mean, rstd, rows, C, eps);
+#define DPA_LN_FWD(NCH_) hipLaunchKernelGGL(layernorm_fwd_kernel<NCH_>, dim3((unsigned)blocks), dim3(256), 0, st, \
+        (const unsigned short*)x, g, b, (unsigned short*)y, mean, rstd, rows, C, eps)
+    if (C <= 512) DPA_LN_FWD(1); else if (C <= 1024) DPA_LN_FWD(2); else DPA_LN_FWD(4);
+#undef DPA_LN_FWD
 }
 
 void layernorm_bwd(const void* dy, const void* x, const float* g, const float* mean, const float* rstd,
                    void* dx, float* dg_partial, float* db_partial, int partial_rows, long rows, int C, hipStream_t st) {
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(partial_rows), dim3(256), 0, st, (const unsigned short*)dy,
-                       (const unsigned short*)x, g, mean, rstd, (unsigned short*)dx, dg_partial, db_partial, rows, C);
+#define DPA_LN_BWD(NCH_) hipLaunchKernelGGL(layernorm_bwd_kernel<NCH_>, dim3(partial_rows), dim3(256), 0, st, \
+        (const unsigned short*)dy, (const unsigned short*)x, g, mean, rstd, (unsigned short*)dx, dg_partial, db_partial, rows, C)
+    if (C <= 512) DPA_LN_BWD(1); else if (C <= 1024) DPA_LN_BWD(2); else DPA_LN_BWD(4);
+#undef DPA_LN_BWD
 }
 
 void reduce_partials(const float* partial, int rows, int C, float* out, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 15) / 16), dim3(256), 0, st, partial, rows, C, out, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 15) / 16, 1), dim3(256), 0, st, partial, rows, C, out, out, accumulate);
+}
+
+void reduce_partials2(const float* partial, int rows, int C, float* out_a, float* out_b, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((C + 15) / 16, 2), dim3(256), 0, st, partial, rows, C, out_a, out_b, accumulate);
 }
 
 void embedding_fwd(const int64_t* tok, const void* wte, const void* wpe, void* y, long B, int T, int C, long V, hipStream_t st) {

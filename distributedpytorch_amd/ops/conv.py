@@ -57,24 +57,26 @@ class _ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = ctx.wt if ctx.wt is not None else C.transpose_filter(w)
             dx = C.conv_dgrad(dy, wt, x.shape[1], x.shape[2], stride, pad, None, None)
-        weight = ctx.weight
+        weight, bias = ctx.weight, ctx.bias
+        # bias gradient = column sums of dy: produced inside the wgrad kernel (one more MFMA against a tile of
+        # ones) when a weight gradient is computed anyway, by the column-sum kernels otherwise
+        db_tgt = None
+        if bias is not None and bias.requires_grad:
+            db_tgt = _sink.target(bias)
+            if db_tgt is None:
+                db = db_tgt = torch.zeros(bias.shape, dtype=torch.float32, device=bias.device)
         if weight.requires_grad:
             tgt = _sink.target(weight)
             if tgt is not None:
-                C.conv_wgrad(x, dy, tgt.view(w.shape), stride, pad)  # accumulate straight into the flat grad buffer
+                C.conv_wgrad(x, dy, tgt.view(w.shape), stride, pad, db_tgt)  # accumulate straight into the flat grad buffer
                 _sink.ready(weight)
             else:
                 dw = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)
-                C.conv_wgrad(x, dy, dw.view(w.shape), stride, pad)
-        bias = ctx.bias
-        if bias is not None and bias.requires_grad:
-            tgt = _sink.target(bias)
-            if tgt is not None:
-                C.colsum(dy, tgt)
-                _sink.ready(bias)
-            else:
-                db = torch.zeros(bias.shape, dtype=torch.float32, device=bias.device)
-                C.colsum(dy, db)
+                C.conv_wgrad(x, dy, dw.view(w.shape), stride, pad, db_tgt)
+        elif db_tgt is not None:
+            C.colsum(dy, db_tgt)
+        if db_tgt is not None and db is None:
+            _sink.ready(bias)
         return dx, dw, None, db, None, None, None, None, None, None, None
 
 

@@ -109,7 +109,12 @@ class _LayerNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         C = _ext.load()
         x, mean, rstd = ctx.saved_tensors
-        dx, dg, db = C.layernorm_bwd(dy.contiguous(), x, ctx.gamma.detach(), mean, rstd)
+        tg, tb = _sink.target(ctx.gamma), _sink.target(ctx.beta)
+        if tg is not None and tb is not None:       # the fold kernel adds straight into the flat gradient buffer
+            dx, _, _ = C.layernorm_bwd(dy.contiguous(), x, ctx.gamma.detach(), mean, rstd, tg, tb)
+            _sink.ready(ctx.gamma); _sink.ready(ctx.beta)
+            return dx, None, None, None
+        dx, dg, db = C.layernorm_bwd(dy.contiguous(), x, ctx.gamma.detach(), mean, rstd, None, None)
         dg = _grad_out(ctx.gamma, dg) if ctx.gamma.requires_grad else None
         db = _grad_out(ctx.beta, db) if ctx.beta.requires_grad else None
         return dx, dg, db, None

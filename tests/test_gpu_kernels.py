@@ -141,6 +141,29 @@ def test_conv_wgrad_split_k_large():
     _close(dw.view(K, C), ref, 5e-3, 5e-2, "wgrad split-k")
 
 
+@pytest.mark.parametrize("shape", [(4096, 768, 2304), (1000, 64, 64), (2048, 3072, 776), (8, 9, 9, 64, 128)])
+def test_conv_wgrad_bias_gradient(shape):
+    """dbias += column sums of dy, from the wgrad kernel itself (Linear shapes: an MFMA against ones) or from the
+    column-sum fallback (conv shapes); dw must be unaffected."""
+    if len(shape) == 3:
+        M, C, K = shape
+        x = _rand_bf16(M, 1, 1, C, seed=21)
+        dy = _rand_bf16(M, 1, 1, K, scale=0.1, seed=22)
+        R, pad = 1, 0
+    else:
+        N, H, W, C, K = shape
+        x = _rand_bf16(N, H, W, C, seed=21)
+        dy = _rand_bf16(N, H, W, K, scale=0.1, seed=22)
+        R, pad = 3, 1
+    dw = torch.zeros(K, R, R, C, device=DEV)
+    dw_ref = torch.zeros(K, R, R, C, device=DEV)
+    db = torch.full((K,), 0.25, device=DEV)
+    _C().conv_wgrad(x, dy, dw, 1, pad, db)
+    _C().conv_wgrad(x, dy, dw_ref, 1, pad)
+    _close(db, dy.float().reshape(-1, K).sum(0) + 0.25, 2e-3, 2e-2, "dbias")
+    _close(dw, dw_ref, 1e-4, 1e-3, "dw beside dbias")
+
+
 def test_colsum():
     x = _rand_bf16(1000, 1000, seed=11)
     out = torch.ones(1000, device=DEV)
