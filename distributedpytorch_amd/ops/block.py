@@ -19,6 +19,7 @@ import torch
 import os
 
 from . import _ext
+from . import side as _side
 from . import sink as _sink
 
 ENABLED = os.environ.get("DPA_NO_FUSED_BLOCK", "0") != "1"
@@ -63,7 +64,10 @@ def _wt(C, conv):
 def _wgrad(C, conv, x, dy, grads, slot):
     tgt = _sink.target(conv.weight)
     if tgt is not None:
-        C.conv_wgrad(x, dy, tgt, conv.stride, conv.padding)
+        if _side.active(x):         # off the critical path: overlaps the BN-backward / dgrad chain (ops/side.py)
+            _side.run(lambda: C.conv_wgrad(x, dy, tgt, conv.stride, conv.padding), (x, dy))
+        else:
+            C.conv_wgrad(x, dy, tgt, conv.stride, conv.padding)
         _sink.ready(conv.weight)
     else:
         dw = torch.zeros(conv.weight.shape, dtype=torch.float32, device=x.device)
@@ -132,6 +136,9 @@ class _BottleneckFn(torch.autograd.Function):
             d3 = C.conv_bnb_apply(a2, w3, 1, 0, dout, k3, co[2], co[3], co[4])
         else:
             d3 = _bn_bwd(C, blk.bn3, dout, k3, c3, m3, i3, True, grads, 7)
+        # each wgrad goes to the side stream BEFORE the dgrad that shares its operand is enqueued: the two GEMMs
+        # run side by side and the wgrad's tail overlaps the next BatchNorm backward (measured better than
+        # enqueueing it after the dgrad, and better than keeping the HBM-bound stage-1/2 1x1 wgrads in line)
         _wgrad(C, blk.conv3, a2, d3, grads, 6)
         da2 = C.conv_dgrad(d3, _wt(C, blk.conv3), a2.shape[1], a2.shape[2], 1, 0, None, None)
         d2 = _bn_bwd(C, blk.bn2, da2, k2, c2, m2, i2, True, grads, 4)

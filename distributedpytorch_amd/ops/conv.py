@@ -17,6 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _ext
+from . import side as _side
 from . import sink as _sink
 
 
@@ -67,8 +68,12 @@ class _ConvFn(torch.autograd.Function):
                 db = db_tgt = torch.zeros(bias.shape, dtype=torch.float32, device=bias.device)
         if weight.requires_grad:
             tgt = _sink.target(weight)
-            if tgt is not None:
-                C.conv_wgrad(x, dy, tgt.view(w.shape), stride, pad, db_tgt)  # accumulate straight into the flat grad buffer
+            if tgt is not None:     # accumulate straight into the flat grad buffer, off the critical path (ops/side.py)
+                if _side.active(x) and (db_tgt is None or db is None):
+                    tv = tgt.view(w.shape)
+                    _side.run(lambda: C.conv_wgrad(x, dy, tv, stride, pad, db_tgt), (x, dy))
+                else:
+                    C.conv_wgrad(x, dy, tgt.view(w.shape), stride, pad, db_tgt)
                 _sink.ready(weight)
             else:
                 dw = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)

@@ -57,7 +57,8 @@ class FusedSGD:
         f = self.flat
         gs = self.grad_scale if grad_scale is None else grad_scale
         if f.device.type == "cuda":
-            from .ops import _ext
+            from .ops import _ext, side
+            side.join(f.device)             # weight gradients may still be in flight on the side stream
             C = _ext.load()
             if len(self.segments) > 1 and self._seg_ends is None:       # device-side weight-decay table, built once
                 self._seg_ends = torch.tensor([b for _, b, _ in self.segments], dtype=torch.int64, device=f.device)
@@ -129,7 +130,8 @@ class FusedAdamW:
         self.steps += 1
         b1, b2 = self.betas
         if f.device.type == "cuda":
-            from .ops import _ext
+            from .ops import _ext, side
+            side.join(f.device)
             _ext.load().adamw(f.master, f.grad, self.m, self.v, f.lp, self.lr, b1, b2, self.eps, self.weight_decay, gs,
                               self.steps, zero_grad)
             f.refresh_transposed()

@@ -27,6 +27,7 @@ import torch
 import torch.nn as nn
 
 from .. import comm as _comm
+from ..ops import side as _side
 from ..ops import sink as _sink
 from .flat import Bucket, FlatParams
 
@@ -118,6 +119,8 @@ class DataParallel:
 
     def _launch(self, b: Bucket) -> None:
         view = self.flat.grad[b.start:b.end]
+        if view.is_cuda:
+            _side.join(view.device)       # weight gradients are produced on the side stream (ops/side.py)
         b.work = self.comm.all_reduce(view, async_op=True)
         self._launched.append(b)
         self.stats["allreduce_calls"] += 1
@@ -128,6 +131,8 @@ class DataParallel:
         """Call after backward, before the optimizer: launches any bucket that did not
         complete through hooks (unused parameters) and waits for all reductions.  The
         wait only orders the compute stream behind RCCL's stream - no host block."""
+        if self.flat.device.type == "cuda":
+            _side.join(self.flat.device)
         if self._sync:
             for b in self.buckets:
                 if b.work is None:

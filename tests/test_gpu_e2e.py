@@ -74,6 +74,34 @@ def test_fused_block_matches_op_by_op_path():
         _compare_paths(l1, g1, d1, l2, g2, d2)
 
 
+def test_side_stream_wgrad_matches_in_line_wgrad():
+    """Weight gradients launched on the side stream (ops/side.py) equal the in-line ones, and are complete when
+    backward() returns (end-of-backward join) as well as after DataParallel.finish()."""
+    from distributedpytorch_amd.models import resnet
+    from distributedpytorch_amd.ops import side, sink
+    from distributedpytorch_amd.parallel.dp import DataParallel
+    x = torch.randn(16, 3, 64, 64, device=DEV); y = torch.randint(0, 16, (16,), device=DEV)
+    got = []
+    keep = side.ENABLED
+    try:
+        for enabled in (True, False):
+            side.ENABLED = enabled
+            torch.manual_seed(4)
+            m = resnet.tiny_resnet().to(DEV).train()
+            dp = DataParallel(m)
+            m.loss(x, y).backward()
+            g_after_backward = dp.flat.grad.clone()
+            dp.finish()
+            got.append((g_after_backward, dp.flat.grad.clone()))
+            sink.uninstall()
+    finally:
+        side.ENABLED = keep
+    (a0, a1), (b0, b1) = got
+    assert torch.equal(a0, a1) and torch.equal(b0, b1)          # nothing was still in flight after backward()
+    cos = torch.nn.functional.cosine_similarity(a1, b1, dim=0).item()
+    assert cos > 0.999 and ((a1 - b1).norm() / b1.norm()).item() < 0.05, cos
+
+
 def _compare_paths(l1, g1, d1, l2, g2, d2):
     assert abs(l1 - l2) < 1e-3
     # The BN statistics are summed with fp32 atomics (order varies run to run), so an activation
