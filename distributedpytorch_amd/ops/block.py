@@ -32,6 +32,7 @@ ENABLED = os.environ.get("DPA_NO_FUSED_BLOCK", "0") != "1"
 # kernels reach ~5 TB/s - so it is a MEMORY-saving option (off by default), not a speed-up, until the epilogue
 # is as good a streamer as norm.hip.
 RECOMPUTE_MIN_BYTES = int(float(os.environ.get("DPA_RECOMPUTE_MB", "1e12")) * 2 ** 20)
+_DS_SIDE = os.environ.get("DPA_DS_SIDE", "1") != "0"
 
 
 def _conv_bn_fwd(C, conv, bn, x, relu, residual=None):
@@ -61,10 +62,14 @@ def _wt(C, conv):
     return wt if wt is not None else C.transpose_filter(conv.weight_lp)
 
 
-def _wgrad(C, conv, x, dy, grads, slot):
+def need_dx_early(ctx) -> bool:
+    return bool(ctx.needs_input_grad[0])
+
+
+def _wgrad(C, conv, x, dy, grads, slot, in_line=False):
     tgt = _sink.target(conv.weight)
     if tgt is not None:
-        if _side.active(x):         # off the critical path: overlaps the BN-backward / dgrad chain (ops/side.py)
+        if _side.active(x) and not in_line:   # off the critical path: overlaps the BN-backward / dgrad chain (ops/side.py)
             _side.run(lambda: C.conv_wgrad(x, dy, tgt, conv.stride, conv.padding), (x, dy))
         else:
             C.conv_wgrad(x, dy, tgt, conv.stride, conv.padding)
@@ -80,13 +85,21 @@ class _BottleneckFn(torch.autograd.Function):
     def forward(ctx, x, blk, *params):
         C = _ext.load()
         ds = blk.downsample is not None
-        if ds:
+        ds_done = None
+        if ds and _DS_SIDE and _side.active(x):
+            # the projection shortcut is independent of conv1 -> conv2: it runs on the side stream beside them
+            box = []
+            ds_done = _side.run(lambda: box.append(_conv_bn_fwd(C, blk.downsample[0], blk.downsample[1], x, False)), (x,))
+            cd, idn, md, isd, _ = box[0]
+        elif ds:
             cd, idn, md, isd, _ = _conv_bn_fwd(C, blk.downsample[0], blk.downsample[1], x, False)
         else:
             cd = md = isd = None
             idn = x
         c1, a1, m1, i1, k1 = _conv_bn_fwd(C, blk.conv1, blk.bn1, x, True)
         c2, a2, m2, i2, k2 = _conv_bn_fwd(C, blk.conv2, blk.bn2, a1, True)
+        if ds_done is not None:
+            _side.wait(ds_done, (cd, idn, md, isd))
         conv3, bn3 = blk.conv3, blk.bn3
         out_bytes = a2.numel() // a2.shape[-1] * conv3.weight_lp.shape[0] * 2
         recompute = out_bytes >= RECOMPUTE_MIN_BYTES and conv3.stride == 1 and conv3.padding == 0
@@ -121,6 +134,20 @@ class _BottleneckFn(torch.autograd.Function):
         grads = [None] * n_params          # order: conv1.w bn1.w bn1.b conv2.w bn2.w bn2.b conv3.w bn3.w bn3.b [ds.w dsbn.w dsbn.b]
         # bn3 behind the residual join: the masked dout is both bn3's incoming gradient and the gradient of the
         # shortcut branch; it is never materialised (consumers apply the bit mask k3 themselves)
+        ds_done, ds_box = None, []
+        if (ds and need_dx_early(ctx) and _DS_SIDE and _side.active(dout)
+                and _sink.target(blk.downsample[0].weight) is not None and _sink.target(blk.downsample[1].weight) is not None):
+            # the projection shortcut's backward (BN backward, wgrad, dgrad) depends on dout only: the whole branch
+            # runs on the side stream beside the main branch and meets it again in the last dgrad's epilogue
+            cd_, md_, isd_ = sv[15:18]
+            dconv_ = blk.downsample[0]
+
+            def ds_branch():
+                dd_ = _bn_bwd(C, blk.downsample[1], dout, k3, cd_, md_, isd_, True, grads, 10)
+                _wgrad(C, dconv_, x, dd_, grads, 9, in_line=True)
+                ds_box.append(C.conv_dgrad(dd_, _wt(C, dconv_), x.shape[1], x.shape[2], dconv_.stride, 0, None, None))
+                ds_box.append(dd_)
+            ds_done = _side.run(ds_branch, (dout, k3, cd_, md_, isd_, x))
         if ctx.recompute:
             bn3, w3 = blk.bn3, blk.conv3.weight_lp
             sb = bn3.stats_buffer_bwd(dout.device)
@@ -149,7 +176,10 @@ class _BottleneckFn(torch.autograd.Function):
         _wgrad(C, blk.conv1, x, d1, grads, 0)
         dx = None
         need_dx = ctx.needs_input_grad[0]
-        if ds:
+        if ds_done is not None:
+            _side.wait(ds_done, ds_box)
+            dx = C.conv_dgrad(d1, _wt(C, blk.conv1), x.shape[1], x.shape[2], 1, 0, ds_box[0], None)
+        elif ds:
             cd, md, isd = sv[15:18]
             dconv = blk.downsample[0]
             dd = _bn_bwd(C, blk.downsample[1], dout, k3, cd, md, isd, True, grads, 10)   # "relu" = the join's mask

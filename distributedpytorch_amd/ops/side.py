@@ -38,9 +38,9 @@ def _stream(index: int) -> "torch.cuda.Stream":
     return s
 
 
-def run(fn: Callable[[], None], keep: Sequence[torch.Tensor]) -> None:
+def run(fn: Callable[[], None], keep: Sequence[torch.Tensor]) -> "torch.cuda.Event":
     """Launch ``fn`` (which enqueues kernels reading ``keep``) on the side stream, after everything enqueued
-    on the current stream so far."""
+    on the current stream so far.  Returns the event marking its completion (see ``wait``)."""
     index = keep[0].device.index
     side = _stream(index)
     side.wait_stream(torch.cuda.current_stream(index))
@@ -59,6 +59,18 @@ def run(fn: Callable[[], None], keep: Sequence[torch.Tensor]) -> None:
             pass
     while _pending and _pending[0][0].query():      # drop references the side stream is done with
         _pending.popleft()
+    return done
+
+
+def wait(done: "torch.cuda.Event", produced: Sequence[torch.Tensor] = ()) -> None:
+    """Order the current stream behind one side launch.  ``produced`` are tensors that launch ALLOCATED (they
+    belong to the side stream's allocator pool): they are marked as used by the current stream so that their
+    memory is not recycled under the compute-stream kernels that read them."""
+    cur = torch.cuda.current_stream()
+    cur.wait_event(done)
+    for t in produced:
+        if t is not None:
+            t.record_stream(cur)
 
 
 def join(device=None) -> None:
