@@ -43,10 +43,15 @@ def _data(shape, classes, n, seed=7):
 
 def dp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, bucket_kb, steps, mode="hooks", backend="gloo"):
     """Each rank takes its shard of ONE global batch; writes reduced grads + params.
-    backend "nccl": one GPU per rank over RCCL (multi-GPU boxes only; tests/test_multi_gpu.py)."""
+    backend "nccl": one GPU per rank over RCCL (multi-GPU boxes only; tests/test_multi_gpu.py);
+    "gloo_gpu": all ranks share GPU 0 and reduce over gloo (tests/test_gpu_e2e.py)."""
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
+    elif backend == "gloo_gpu":             # every rank on GPU 0, collectives over gloo: the GPU engine (HIP kernels,
+        torch.cuda.set_device(0)            # side stream, bucket launches) at world size > 1 on a one-GPU box
+        device = torch.device("cuda", 0)
+        backend = "gloo"
     else:
         device = torch.device("cpu")
     comm = dcomm.init_process_group(backend, url, global_rank, world_size, 60.0, device)
