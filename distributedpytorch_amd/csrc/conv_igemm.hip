@@ -11,10 +11,12 @@
 //
 // Block = 4 waves (64-wide), each wave a 64(pixel) x 64(channel) tile as 4x4 MFMA
 // tiles; block tile 128x128 (2x2 waves) or 256x64 (4x1 waves, for 64-channel
-// layers).  K step 32.  Register-staged double-buffered LDS (issue-early /
-// write-late, one barrier per K step); LDS tiles XOR-swizzled so the ds_read_b128
-// fragment reads are bank-conflict free.  Epilogue goes through LDS so that global
-// stores are 16 B per lane over full NHWC rows.  Optional fused epilogue work:
+// layers).  K step 32, one barrier per K step.  Operand tiles go global -> LDS by DMA
+// (buffer_load ... lds; descriptor range checks supply the zeros of padding and tile
+// edges), double- or triple-buffered; LDS tiles are XOR-swizzled so the ds_read_b128
+// fragment reads are bank-conflict free.  Register-staged variants are kept selectable
+// (STG below; measurements in docs/DESIGN.md section 6).  Epilogue goes through LDS so that
+// global stores are 16 B per lane over full NHWC rows.  Optional fused epilogue work:
 //   * per-channel (sum, sum of squares) of the output for a following BatchNorm, added
 //     with fp32 atomics into a small replicated buffer (removes one full read of the
 //     activation tensor per layer);
@@ -44,17 +46,17 @@ __device__ __forceinline__ int swz4(int row) {  // conflict-free chunk swizzle f
 }
 
 // ONE: 1x1 filter, no padding (a plain GEMM over gathered rows): no tap arithmetic in the loop.
-// Two pipelining variants.  RING: two register sets, loads two tiles ahead, 3 waves per SIMD (<= 168
-// VGPRs; the 256x64 general-gather variant runs at 2).  !RING: one register set (write tile t+1 right
-// after the barrier, re-issue t+2 at once), <= 128 VGPRs = 4 waves per SIMD: better for grids of very
-// many short workgroups, where occupancy hides more than prefetch depth does (use_ring() below).
-// Accumulators stay in VGPRs in both (no AGPR copies).
+// STG selects how the operand tiles reach LDS (host: staging(); DPA_IGEMM_STG forces one).  Accumulators stay in
+// VGPRs in all of them (no AGPR copies):
 //   STG 0: one register set, 4 waves/SIMD;  STG 1: register ring, 3 waves/SIMD;
 //   STG 2: LDS-DMA (buffer_load ... lds): the gather lands in LDS without passing through VGPRs or
 //          ds_write_b128 (13 LDS-pipe cycles per KiB) - with register staging the LDS pipe, not the MFMA pipe,
 //          is the busiest unit of this kernel (PMC: SQ_ACTIVE_INST_LDS 71 % on a 768-deep GEMM).  The lane ->
 //          LDS slot map of the DMA is linear, so each lane fetches the chunk that belongs in its slot
 //          (the XOR swizzle moves to the source address); padding / tile edges still read zeros by range check.
+//          Default for large grids (4 workgroups resident per CU).
+//   STG 3: the same DMA issued from inline assembly with counted s_waitcnt vmcnt(N): two tiles in flight over
+//          three LDS buffers (3 workgroups per CU).  Default for small grids.  (4, 5: depth 4 / 6, not instantiated.)
 constexpr int dma_depth(int stg) { return stg == 3 ? 2 : stg == 4 ? 4 : stg == 5 ? 6 : 1; }
 constexpr int igemm_lds_bytes(int wp, int wc, int stg) {
     const int stage = (wp + wc) * 64 * BK * 2, epi = wp * 64 * (wc * 64 + 8) * 2;
