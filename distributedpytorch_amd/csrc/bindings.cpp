@@ -398,6 +398,56 @@ Tensor relu_mask_mul(const Tensor& dy, const Tensor& mask) {
     return out;
 }
 
+// stem: (pooled y, idx) = maxpool3x3/2(relu(x * scale + shift)), x = raw conv output [N,H,W,C]
+std::vector<Tensor> bn_relu_maxpool_fwd(const Tensor& x, const Tensor& scale, const Tensor& shift) {
+    CHECK_BF16(x); CHECK_F32(scale); CHECK_F32(shift);
+    TORCH_CHECK(x.dim() == 4 && x.size(3) % 8 == 0 && scale.numel() == x.size(3) && shift.numel() == x.size(3), "bn_relu_maxpool_fwd: shapes");
+    TORCH_CHECK(x.numel() < (1ll << 31), "bn_relu_maxpool_fwd: tensor too large for 32-bit indexing");
+    const int64_t N = x.size(0), H = x.size(1), W = x.size(2), C = x.size(3);
+    const int64_t Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    Guard g(x);
+    Tensor y = torch::empty({N, Ho, Wo, C}, x.options());
+    Tensor idx = torch::empty({N, Ho, Wo, C}, x.options().dtype(at::kByte));
+    dpa::bn_relu_maxpool_fwd(x.data_ptr(), scale.data_ptr<float>(), shift.data_ptr<float>(), y.data_ptr(), idx.data_ptr<uint8_t>(),
+                             N, H, W, C, Ho, Wo, cur_stream());
+    return {y, idx};
+}
+
+// backward of the above down to the conv output: returns (dx, dgamma, dbeta); accumulators / stats_buf as bn_backward
+std::vector<Tensor> pool_bn_backward(const Tensor& dp, const Tensor& idx, const Tensor& x, const Tensor& gamma, const Tensor& mean,
+                                     const Tensor& invstd, const c10::optional<Tensor>& dgamma_acc,
+                                     const c10::optional<Tensor>& dbeta_acc, const Tensor& stats_buf) {
+    CHECK_BF16(dp); CHECK_BF16(x); CHECK_F32(gamma); CHECK_F32(mean); CHECK_F32(invstd); CHECK_F32(stats_buf);
+    CHECK_DEV(idx); CHECK_CONTIG(idx);
+    TORCH_CHECK(x.dim() == 4 && dp.dim() == 4, "pool_bn_backward: NHWC tensors expected");
+    const int64_t N = x.size(0), H = x.size(1), W = x.size(2), C = x.size(3), Ho = dp.size(1), Wo = dp.size(2);
+    TORCH_CHECK(dp.size(0) == N && dp.size(3) == C && (H - 1) / 2 + 1 == Ho && (W - 1) / 2 + 1 == Wo && idx.numel() == dp.numel() &&
+                idx.scalar_type() == at::kByte, "pool_bn_backward: geometry");
+    TORCH_CHECK(C % 8 == 0 && C <= 2048 && gamma.numel() == C && mean.numel() == C && invstd.numel() == C && x.numel() < (1ll << 31),
+                "pool_bn_backward: channels");
+    TORCH_CHECK(stats_buf.dim() == 3 && stats_buf.size(1) == 2 && stats_buf.size(2) == C, "pool_bn_backward: stats_buf must be [rows,2,C]");
+    Guard g(x);
+    const int rows = stats_buf.size(0);
+    const int64_t P = N * H * W;
+    Tensor stats = stats_buf;
+    dpa::pool_bn_bwd_stats(dp.data_ptr(), idx.data_ptr<uint8_t>(), x.data_ptr(), mean.data_ptr<float>(), invstd.data_ptr<float>(),
+                           stats.data_ptr<float>(), N, H, W, C, Ho, Wo, rows, cur_stream());
+    Tensor co = torch::empty({5, C}, x.options().dtype(at::kFloat));
+    float* o = co.data_ptr<float>();
+    float* dg = o; float* db = o + C; int accumulate = 0;
+    if (dgamma_acc.has_value() && dgamma_acc->defined()) {
+        CHECK_F32((*dgamma_acc)); CHECK_F32((*dbeta_acc));
+        TORCH_CHECK(dgamma_acc->numel() == C && dbeta_acc->numel() == C, "pool_bn_backward: accumulate targets");
+        dg = dgamma_acc->data_ptr<float>(); db = dbeta_acc->data_ptr<float>(); accumulate = 1;
+    }
+    dpa::bn_bwd_finalize(stats.data_ptr<float>(), rows, P, C, gamma.data_ptr<float>(), mean.data_ptr<float>(),
+                         invstd.data_ptr<float>(), dg, db, accumulate, o + 2 * C, o + 3 * C, o + 4 * C, 1, 0, cur_stream());
+    Tensor dx = torch::empty_like(x);
+    dpa::pool_bn_bwd_apply(dp.data_ptr(), idx.data_ptr<uint8_t>(), x.data_ptr(), o + 2 * C, o + 3 * C, o + 4 * C, dx.data_ptr(),
+                           N, H, W, C, Ho, Wo, cur_stream());
+    return {dx, co[0], co[1]};
+}
+
 // ---------------------------------------------------------------- pooling / layout / elementwise
 std::vector<Tensor> maxpool_fwd(const Tensor& x) {
     CHECK_BF16(x); TORCH_CHECK(x.dim() == 4 && x.size(3) % 8 == 0, "maxpool: NHWC with C % 8 == 0");
@@ -691,6 +741,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("bn_apply", &bn_apply);
     m.def("relu_mask_mul", &relu_mask_mul);
     m.def("bn_backward", &bn_backward);
+    m.def("bn_relu_maxpool_fwd", &bn_relu_maxpool_fwd);
+    m.def("pool_bn_backward", &pool_bn_backward);
     m.def("maxpool_fwd", &maxpool_fwd);
     m.def("maxpool_bwd", &maxpool_bwd);
     m.def("avgpool_fwd", &avgpool_fwd);

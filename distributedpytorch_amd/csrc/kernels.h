@@ -98,6 +98,14 @@ void bn_bwd_apply(const void* dy, const unsigned char* mask, const void* x, cons
 void relu_mask_mul(const void* dy, const unsigned char* mask, void* out, long n, hipStream_t st);
 
 // ---------------------------------------------------------------- pooling / layout
+// stem: y = maxpool3x3/2(relu(x * scale + shift)) without materialising the activation; idx = winning tap (9: none)
+void bn_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, unsigned char* idx,
+                         int N, int H, int W, int C, int Ho, int Wo, hipStream_t st);
+// ... and its BatchNorm backward, gathering the pooled gradient through idx (no un-pooled gradient tensor)
+void pool_bn_bwd_stats(const void* dp, const unsigned char* idx, const void* x, const float* mean, const float* invstd,
+                       float* stats, int N, int H, int W, int C, int Ho, int Wo, int replicas, hipStream_t st);
+void pool_bn_bwd_apply(const void* dp, const unsigned char* idx, const void* x, const float* coefA, const float* coefB,
+                       const float* coefC, void* dx, int N, int H, int W, int C, int Ho, int Wo, hipStream_t st);
 void maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int Ho, int Wo, hipStream_t st);
 void maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C, int Ho, int Wo, hipStream_t st);
 void avgpool_fwd(const void* x, void* y, int N, int HW, int C, hipStream_t st);

@@ -240,6 +240,120 @@ __global__ __launch_bounds__(256) void fold_rows_kernel(const float* __restrict_
     out[(long)blockIdx.y * cols + col] = s;
 }
 
+// ------------------------------------------------------------------ stem: BatchNorm + ReLU + 3x3/2 max pool, fused
+// The stem's activation (N x 112 x 112 x 64 at batch 256: 411 MB) is the largest tensor of the network.  Unfused it
+// is written by bn_apply, read by the pool, and its gradient is written by the pool backward and read twice by the
+// BatchNorm backward.  Fused, neither exists: forward reads the raw conv output through the 3x3 windows and writes
+// only the pooled map plus one byte per pooled element (winning tap 0..8, or 9 = "all taps <= 0": ReLU passes no
+// gradient); backward rebuilds each position's gradient on the fly from the <= 4 windows that contain it.
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const unsigned short* __restrict__ x, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, unsigned short* __restrict__ y,
+                                                                  unsigned char* __restrict__ idx, int N, int H, int W, int C,
+                                                                  int Ho, int Wo) {
+    const int cpr = C / 8;
+    const unsigned total = (unsigned)N * Ho * Wo * cpr;           // < 2^31 (host check)
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned ch = i % cpr;
+        unsigned p = i / cpr;
+        const int wo = (int)(p % Wo); p /= Wo;
+        const int ho = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        float sc[8], sh[8], best[8]; int bi[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = scale[ch * 8 + j]; sh[j] = shift[ch * 8 + j]; best[j] = 0.f; bi[j] = 9; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = ho * 2 - 1 + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) {
+                const int wi = wo * 2 - 1 + s_;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const uint4 v = *(const uint4*)(x + ((size_t)(n * H + hi) * W + wi) * C + ch * 8);
+                float f[8]; unpack8(v, f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = f[j] * sc[j] + sh[j];
+                    if (t > best[j]) { best[j] = t; bi[j] = r * 3 + s_; }   // strictly positive only: ReLU folded in
+                }
+            }
+        }
+        *(uint4*)(y + (size_t)i * 8) = pack8(best);
+        uint2 pk;
+        pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+        pk.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+        *(uint2*)(idx + (size_t)i * 8) = pk;
+    }
+}
+
+// gradient reaching input position (n, hi, wi), channels 8 ch .. 8 ch + 7, through the pooling windows that hold it
+__device__ __forceinline__ void pool_grad_gather(const unsigned short* __restrict__ dp, const unsigned char* __restrict__ idx,
+                                                 int n, int hi, int wi, int ch, int Ho, int Wo, int cpr, float (&g)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+    const int ho_lo = hi >> 1, ho_hi = (hi + 1) >> 1, wo_lo = wi >> 1, wo_hi = (wi + 1) >> 1;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+        if (ho >= Ho) continue;
+        const int r = hi - (ho * 2 - 1);
+        for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+            if (wo >= Wo) continue;
+            const unsigned tap = (unsigned)(r * 3 + (wi - (wo * 2 - 1)));
+            const size_t o = ((size_t)(n * Ho + ho) * Wo + wo) * cpr + ch;
+            const uint2 ik = *(const uint2*)(idx + o * 8);
+            const uint4 dv = *(const uint4*)(dp + o * 8);
+            float d[8]; unpack8(dv, d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned t = ((j < 4 ? ik.x : ik.y) >> ((j & 3) * 8)) & 0xffu;
+                g[j] += t == tap ? d[j] : 0.f;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_bn_bwd_stats_kernel(const unsigned short* __restrict__ dp, const unsigned char* __restrict__ idx,
+                                                                const unsigned short* __restrict__ x, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, float* __restrict__ stats,
+                                                                long P, int C, int H, int W, int Ho, int Wo, int rpb, int replicas) {
+    const int cpr = C / 8;
+    reduce_rows([&](long r, int ch, float (&s)[8], float (&q)[8]) {
+        const unsigned pix = (unsigned)r;
+        const int wi = (int)(pix % (unsigned)W); const unsigned t = pix / (unsigned)W;
+        const int hi = (int)(t % (unsigned)H), n = (int)(t / (unsigned)H);
+        float g[8], xf[8];
+        pool_grad_gather(dp, idx, n, hi, wi, ch, Ho, Wo, cpr, g);
+        const uint4 xv = *(const uint4*)(x + r * C + ch * 8);
+        unpack8(xv, xf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = (xf[j] - mean[ch * 8 + j]) * invstd[ch * 8 + j];
+            s[j] += g[j]; q[j] += g[j] * xh;
+        }
+    }, stats, P, C, rpb, replicas);
+}
+
+__global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const unsigned short* __restrict__ dp, const unsigned char* __restrict__ idx,
+                                                                const unsigned short* __restrict__ x, const float* __restrict__ cA,
+                                                                const float* __restrict__ cB, const float* __restrict__ cC,
+                                                                unsigned short* __restrict__ dx, int N, int H, int W, int C,
+                                                                int Ho, int Wo) {
+    const int cpr = C / 8;
+    const unsigned total = (unsigned)N * H * W * cpr;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int ch = (int)(i % cpr);
+        unsigned p = i / cpr;
+        const int wi = (int)(p % W); p /= W;
+        const int hi = (int)(p % H);
+        const int n = (int)(p / H);
+        float g[8], xf[8], o[8];
+        pool_grad_gather(dp, idx, n, hi, wi, ch, Ho, Wo, cpr, g);
+        { const uint4 v = *(const uint4*)(x + (size_t)i * 8); unpack8(v, xf); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = cA[ch * 8 + j] * g[j] + cB[ch * 8 + j] * xf[j] + cC[ch * 8 + j];
+        *(uint4*)(dx + (size_t)i * 8) = pack8(o);
+    }
+}
+
 inline int stream_grid(long nchunks) {
     long b = (nchunks + 255) / 256;
     if (b > 4096) b = 4096;
@@ -313,6 +427,27 @@ void relu_mask_mul(const void* dy, const unsigned char* mask, void* out, long n,
     const long nchunks = n / 8;
     hipLaunchKernelGGL(relu_mask_mul_kernel, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const unsigned short*)dy, mask,
                        (unsigned short*)out, nchunks);
+}
+
+void bn_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, unsigned char* idx,
+                         int N, int H, int W, int C, int Ho, int Wo, hipStream_t st) {
+    const long total = (long)N * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(stream_grid(total)), dim3(256), 0, st, (const unsigned short*)x, scale,
+                       shift, (unsigned short*)y, idx, N, H, W, C, Ho, Wo);
+}
+
+void pool_bn_bwd_stats(const void* dp, const unsigned char* idx, const void* x, const float* mean, const float* invstd,
+                       float* stats, int N, int H, int W, int C, int Ho, int Wo, int replicas, hipStream_t st) {
+    const long P = (long)N * H * W;
+    hipLaunchKernelGGL(pool_bn_bwd_stats_kernel, dim3(bn_stats_rows(P)), dim3(256), 0, st, (const unsigned short*)dp, idx,
+                       (const unsigned short*)x, mean, invstd, stats, P, C, H, W, Ho, Wo, rows_per_block(P), replicas);
+}
+
+void pool_bn_bwd_apply(const void* dp, const unsigned char* idx, const void* x, const float* coefA, const float* coefB,
+                       const float* coefC, void* dx, int N, int H, int W, int C, int Ho, int Wo, hipStream_t st) {
+    const long total = (long)N * H * W * (C / 8);
+    hipLaunchKernelGGL(pool_bn_bwd_apply_kernel, dim3(stream_grid(total)), dim3(256), 0, st, (const unsigned short*)dp, idx,
+                       (const unsigned short*)x, coefA, coefB, coefC, (unsigned short*)dx, N, H, W, C, Ho, Wo);
 }
 
 }  // namespace dpa

@@ -57,6 +57,8 @@ class Stem(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dim() == 4 and x.shape[1] == 3:          # NCHW image batch -> kernel layout
             x = ops.to_nhwc(x, self.conv1.in_padded)
+        if _block.can_fuse_stem(self, x):
+            return _block.stem(self, x)            # one autograd node; the 112x112 activation is never written
         y = conv_bn(self.conv1, self.bn1, x, relu=True)
         return ops.max_pool_3x3_s2_nhwc(y)
 

@@ -377,3 +377,34 @@ def test_causal_attention_fwd_bwd(B, T, H):
     for i, name in enumerate(("dq", "dk", "dv")):
         # P and dS are rounded to bf16 before the second MFMA product
         _close(g[:, :, i], gr[:, :, i], 3e-2, 3e-2, "attention " + name)
+
+
+@pytest.mark.parametrize("shape", [(4, 32, 32, 64), (3, 17, 23, 16)])
+def test_fused_bn_relu_maxpool_matches_unfused_ops(shape):
+    """bn_relu_maxpool_fwd / pool_bn_backward (the stem node) against bn_apply + maxpool and their backwards."""
+    N, H, W, C = shape
+    C_ = _C()
+    x = _rand_bf16(N, H, W, C, seed=31)
+    gamma = torch.rand(C, device=DEV) + 0.5
+    beta = torch.randn(C, device=DEV) * 0.3
+    xf = x.float()
+    mean = xf.mean((0, 1, 2)); var = xf.var((0, 1, 2), unbiased=False)
+    invstd = torch.rsqrt(var + 1e-5)
+    scale = (gamma * invstd).contiguous(); shift = (beta - mean * gamma * invstd).contiguous()
+    # unfused reference chain on the same kernels
+    a, mask = C_.bn_apply(x, None, scale, shift, True, True)
+    y_ref, idx_ref = C_.maxpool_fwd(a)
+    y, idx = C_.bn_relu_maxpool_fwd(x, scale, shift)
+    assert torch.equal(y, y_ref)
+    dp = _rand_bf16(*y.shape, scale=0.2, seed=32)
+    da = C_.maxpool_bwd(dp, idx_ref, H, W)
+    dx_ref, dg_ref, db_ref = C_.bn_backward(da, mask, x, gamma, mean, invstd, True, None, None, None)
+    sbuf = torch.zeros(32, 2, C, device=DEV)
+    dx, dg, db = C_.pool_bn_backward(dp, idx, x, gamma, mean, invstd, None, None, sbuf)
+    assert float(sbuf.abs().max()) == 0.0                       # finalize re-zeroed the accumulator
+    # the unfused chain rounds the un-pooled gradient (sums of up to 4 pooled gradients) to bf16 before reducing
+    # thousands of them; the fused kernels reduce the fp32 sums - compare at the scale of the sums
+    sc = float(dg_ref.abs().max())
+    _close(dg, dg_ref, 1e-2, 5e-3 * sc, "dgamma")
+    _close(db, db_ref, 1e-2, 5e-3 * max(sc, float(db_ref.abs().max())), "dbeta")
+    _close(dx, dx_ref.float(), 2e-2, 3e-2, "dx", max_bad_frac=1e-3)
