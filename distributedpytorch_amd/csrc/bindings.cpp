@@ -179,8 +179,12 @@ Tensor bn_bwd_coefs(Tensor& stats_buf, int64_t P, const Tensor& gamma, const Ten
 }
 
 // dgrad: dy [N,Ho,Wo,K] bf16, wt [C,R,S,K] bf16 (filter with K and C swapped) -> dx [N,H,W,C]
+// Optional bn_x / bn_mask / bn_stats (stride 1, no addend): the kernel also adds sum(g'), sum(g' * bn_x) per channel
+// into bn_stats ([rows,2,C] fp32, zeroed), g' = dx under the ReLU bit mask bn_mask - the reduction pass of the
+// backward of the BatchNorm whose output this dx is the gradient of (finish with bn_bwd_coefs + bn_bwd_apply).
 Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int64_t stride, int64_t pad,
-                  const c10::optional<Tensor>& addend, const c10::optional<Tensor>& addend_mask) {
+                  const c10::optional<Tensor>& addend, const c10::optional<Tensor>& addend_mask,
+                  const c10::optional<Tensor>& bn_x, const c10::optional<Tensor>& bn_mask, const c10::optional<Tensor>& bn_stats) {
     CHECK_BF16(dy); CHECK_BF16(wt);
     TORCH_CHECK(dy.dim() == 4 && wt.dim() == 4, "conv_dgrad: 4-D tensors expected");
     const int64_t N = dy.size(0), Ho = dy.size(1), Wo = dy.size(2), K = dy.size(3);
@@ -207,7 +211,36 @@ Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int6
     }
     a.N = N; a.H = Ho; a.W = Wo; a.C = K; a.K = C; a.R = R; a.S = S; a.Ho = H; a.Wo = W;
     a.stride = stride; a.pad = pad; a.mode = 1; a.act = 0;
+    if (bn_x.has_value() && bn_x->defined()) {
+        TORCH_CHECK(stride == 1 && a.addend == nullptr, "conv_dgrad: fused BatchNorm statistics need stride 1 and no addend");
+        TORCH_CHECK(bn_mask.has_value() && bn_mask->defined() && bn_stats.has_value() && bn_stats->defined(), "conv_dgrad: bn_mask / bn_stats missing");
+        CHECK_BF16((*bn_x)); CHECK_F32((*bn_stats));
+        TORCH_CHECK(bn_x->numel() == dx.numel() && bn_mask->scalar_type() == at::kByte && bn_mask->is_contiguous() &&
+                    bn_mask->numel() * 8 == dx.numel(), "conv_dgrad: bn_x / bn_mask shapes");
+        TORCH_CHECK(bn_stats->dim() == 3 && bn_stats->size(1) == 2 && bn_stats->size(2) == C, "conv_dgrad: bn_stats must be [rows,2,C]");
+        a.epi = 4; a.ep_src = bn_x->data_ptr(); a.ep_mask_in = bn_mask->data_ptr<uint8_t>();
+        a.ep_stats = bn_stats->data_ptr<float>(); a.ep_stats_rows = (int)bn_stats->size(0);
+    }
     dpa::conv_igemm(a, cur_stream());
+    return dx;
+}
+
+// the apply pass of a BatchNorm backward alone: dx = A * dy' + B * x + C per channel (co = bn_bwd_coefs(...): rows 2..4),
+// dy' = dy under the ReLU bit mask
+Tensor bn_bwd_apply(const Tensor& dy, const c10::optional<Tensor>& mask, const Tensor& x, const Tensor& co, bool relu) {
+    CHECK_BF16(dy); CHECK_BF16(x); CHECK_F32(co);
+    const int64_t C = x.size(-1), P = x.numel() / C;
+    TORCH_CHECK(dy.numel() == x.numel() && co.dim() == 2 && co.size(0) == 5 && co.size(1) == C && C % 8 == 0, "bn_bwd_apply: shapes");
+    const uint8_t* mk = nullptr;
+    if (relu) {
+        TORCH_CHECK(mask.has_value() && mask->defined() && mask->scalar_type() == at::kByte && mask->is_contiguous() &&
+                    mask->numel() * 8 == x.numel(), "bn_bwd_apply: relu needs the uint8 bit mask from bn_apply");
+        mk = mask->data_ptr<uint8_t>();
+    }
+    Guard g(x);
+    Tensor dx = torch::empty_like(x);
+    const float* o = co.data_ptr<float>();
+    dpa::bn_bwd_apply(dy.data_ptr(), mk, x.data_ptr(), o + 2 * C, o + 3 * C, o + 4 * C, dx.data_ptr(), P, C, relu, cur_stream());
     return dx;
 }
 
@@ -725,7 +758,10 @@ void bind_rccl(pybind11::module_& m);         // rccl_comm.cpp
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "distributedpytorch_amd gfx950 kernels";
     m.def("conv_fprop", &conv_fprop);
-    m.def("conv_dgrad", &conv_dgrad);
+    m.def("conv_dgrad", &conv_dgrad, py::arg("dy"), py::arg("wt"), py::arg("H"), py::arg("W"), py::arg("stride"), py::arg("pad"),
+          py::arg("addend"), py::arg("addend_mask"), py::arg("bn_x") = py::none(), py::arg("bn_mask") = py::none(),
+          py::arg("bn_stats") = py::none());
+    m.def("bn_bwd_apply", &bn_bwd_apply);
     m.def("conv_fprop_stats", &conv_fprop_stats);
     m.def("conv_bn_res_relu", &conv_bn_res_relu);
     m.def("conv_bnb_stats", &conv_bnb_stats);

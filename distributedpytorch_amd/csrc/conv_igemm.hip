@@ -407,8 +407,9 @@ __global__ __launch_bounds__(256, igemm_waves_per_simd(WP, ONE, STG)) void conv_
         eoff[pss] = (m < M && co < a.K) ? pix * (unsigned)a.K + (unsigned)co : ~0u;   // output < 2^31 elements (host check)
     }
     const bool epi_on = MODE == 0 && a.epi != 0;
-    const void* pre_src = epi_on ? a.ep_src : a.addend;
-    const unsigned char* pre_msk = epi_on ? (a.epi == 1 ? nullptr : a.ep_mask_in) : a.addend_mask;
+    const bool epi_dgrad_stats = MODE == 1 && a.epi == 4;       // dgrad + reduction pass of the next BatchNorm backward
+    const void* pre_src = (epi_on || epi_dgrad_stats) ? a.ep_src : a.addend;
+    const unsigned char* pre_msk = epi_on ? (a.epi == 1 ? nullptr : a.ep_mask_in) : epi_dgrad_stats ? a.ep_mask_in : a.addend_mask;
     u32x4 pre[NPASS];
     unsigned pmk[NPASS];
     if (pre_src != nullptr) {
@@ -483,6 +484,26 @@ __global__ __launch_bounds__(256, igemm_waves_per_simd(WP, ONE, STG)) void conv_
     //   epi 2: no output; adds sum(g), sum(g * c) per channel into ep_stats        (BN backward, reduction pass)
     //   epi 3: y = ep_a[ch] * g + ep_b[ch] * c + ep_c[ch]                          (BN backward, apply pass)
     // with c = the bf16-rounded conv output of this tile, g = ep_src under the bit mask ep_mask_in.
+    // per-thread (sum, sum-product) partials of 8 channels -> ep_stats: fold the RPP row groups through LDS (the
+    // staged tile is dead once everyone has read it), then one atomic per channel and statistic
+    auto fold_stats = [&](const float (&s8)[8], const float (&q8)[8]) {
+        __syncthreads();
+        float* red = (float*)smem;                       // [2][RPP][BC]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            red[(0 * RPP + orow) * BC + och * 8 + j] = s8[j];
+            red[(1 * RPP + orow) * BC + och * 8 + j] = q8[j];
+        }
+        __syncthreads();
+        for (int o = tid; o < 2 * BC; o += 256) {
+            const int st_ = o / BC, ch = o - st_ * BC;
+            float t = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < RPP; ++r) t += red[(st_ * RPP + r) * BC + ch];
+            if (c0 + ch < a.K)
+                atomicAdd(a.ep_stats + ((long)(tile_p % a.ep_stats_rows) * 2 + st_) * a.K + c0 + ch, t);
+        }
+    };
     if (epi_on) {
         float ea[8], eb[8], ec[8];
 #pragma unroll
@@ -528,28 +549,37 @@ __global__ __launch_bounds__(256, igemm_waves_per_simd(WP, ONE, STG)) void conv_
                 }
             }
         }
-        if (a.epi == 2) {
-            // fold the RPP row groups through LDS (the staged tile is dead once everyone has read it)
-            __syncthreads();
-            float* red = (float*)smem;                       // [2][RPP][BC]
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                red[(0 * RPP + orow) * BC + och * 8 + j] = s8[j];
-                red[(1 * RPP + orow) * BC + och * 8 + j] = q8[j];
-            }
-            __syncthreads();
-            for (int o = tid; o < 2 * BC; o += 256) {
-                const int st_ = o / BC, ch = o - st_ * BC;
-                float t = 0.f;
-#pragma unroll 8
-                for (int r = 0; r < RPP; ++r) t += red[(st_ * RPP + r) * BC + ch];
-                if (c0 + ch < a.K)
-                    atomicAdd(a.ep_stats + ((long)(tile_p % a.ep_stats_rows) * 2 + st_) * a.K + c0 + ch, t);
-            }
-        }
+        if (a.epi == 2) fold_stats(s8, q8);
         return;
     }
     if (yg == nullptr) return;          // statistics-only pass
+
+    // epi 4 (dgrad, stride 1): besides writing the tile g = dL/d(activation), accumulate what the BatchNorm in front
+    // of that activation needs for ITS backward - sum(g'), sum(g' * c) with g' = g under the ReLU bit mask
+    // ep_mask_in and c = ep_src the BatchNorm's raw input - so no separate reduction pass re-reads g.
+    if (epi_dgrad_stats) {
+        float s8[8], q8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s8[j] = 0.f; q8[j] = 0.f; }
+#pragma unroll
+        for (int pss = 0; pss < NPASS; ++pss) {
+            const int row = pss * RPP + orow;
+            if (eoff[pss] != ~0u) {
+                const uint4 v = *(const uint4*)(cs + row * CS + och * 8);
+                *(uint4*)(yg + (size_t)eoff[pss]) = v;
+                float g[8], c[8];
+                unpack8(v, g); unpack8(__builtin_bit_cast(uint4, pre[pss]), c);
+                const unsigned mk = pmk[pss];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gm = ((mk >> j) & 1u) ? g[j] : 0.f;
+                    s8[j] += gm; q8[j] += gm * c[j];
+                }
+            }
+        }
+        fold_stats(s8, q8);
+        return;
+    }
 
 #pragma unroll
     for (int pss = 0; pss < NPASS; ++pss) {

@@ -56,6 +56,30 @@ def _bn_bwd(C, bn, dy, mask, x_raw, mean, invstd, relu, grads, slot):
     return dx
 
 
+_DGRAD_BN_STATS = os.environ.get("DPA_NO_DGRAD_BN_STATS", "0") != "1"
+
+
+def _dgrad_then_bn_bwd(C, conv, bn, dy, hw, mask, x_raw, mean, invstd, grads, slot):
+    """``da = dgrad(conv, dy)`` followed by the backward of the BatchNorm (+ReLU) whose output ``da`` is the gradient
+    of.  At stride 1 the dgrad kernel's epilogue also produces that BatchNorm's reduction pass (sum g', sum g' * x
+    from the tile it is about to write), so the stand-alone statistics kernel - one full read of ``da`` and of the
+    BatchNorm input - is skipped: finalize + apply only."""
+    tg, tb = _sink.target(bn.weight), _sink.target(bn.bias)
+    sunk = tg is not None and tb is not None
+    if _DGRAD_BN_STATS and conv.stride == 1:
+        sb = bn.stats_buffer_bwd(dy.device)
+        da = C.conv_dgrad(dy, _wt(C, conv), hw[0], hw[1], 1, conv.padding, None, None, x_raw, mask, sb)
+        co = C.bn_bwd_coefs(sb, da.numel() // da.shape[-1], bn.weight.detach(), mean, invstd,
+                            tg if sunk else None, tb if sunk else None)
+        if sunk:
+            _sink.ready(bn.weight); _sink.ready(bn.bias)
+        else:
+            grads[slot], grads[slot + 1] = co[0], co[1]
+        return C.bn_bwd_apply(da, mask, x_raw, co, True)
+    da = C.conv_dgrad(dy, _wt(C, conv), hw[0], hw[1], conv.stride, conv.padding, None, None)
+    return _bn_bwd(C, bn, da, mask, x_raw, mean, invstd, True, grads, slot)
+
+
 def _wt(C, conv):
     """Filter with K and C swapped for dgrad: the twin FlatParams keeps current, else transposed on the spot."""
     wt = getattr(conv, "weight_lp_t", None)
@@ -167,12 +191,9 @@ class _BottleneckFn(torch.autograd.Function):
         # run side by side and the wgrad's tail overlaps the next BatchNorm backward (measured better than
         # enqueueing it after the dgrad, and better than keeping the HBM-bound stage-1/2 1x1 wgrads in line)
         _wgrad(C, blk.conv3, a2, d3, grads, 6)
-        da2 = C.conv_dgrad(d3, _wt(C, blk.conv3), a2.shape[1], a2.shape[2], 1, 0, None, None)
-        d2 = _bn_bwd(C, blk.bn2, da2, k2, c2, m2, i2, True, grads, 4)
+        d2 = _dgrad_then_bn_bwd(C, blk.conv3, blk.bn2, d3, a2.shape[1:3], k2, c2, m2, i2, grads, 4)
         _wgrad(C, blk.conv2, a1, d2, grads, 3)
-        da1 = C.conv_dgrad(d2, _wt(C, blk.conv2), a1.shape[1], a1.shape[2],
-                           blk.conv2.stride, blk.conv2.padding, None, None)
-        d1 = _bn_bwd(C, blk.bn1, da1, k1, c1, m1, i1, True, grads, 1)
+        d1 = _dgrad_then_bn_bwd(C, blk.conv2, blk.bn1, d2, a1.shape[1:3], k1, c1, m1, i1, grads, 1)
         _wgrad(C, blk.conv1, x, d1, grads, 0)
         dx = None
         need_dx = ctx.needs_input_grad[0]
