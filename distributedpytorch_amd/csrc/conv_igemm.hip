@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256, igemm_waves_per_simd(WP, ONE, STG)) void conv_
         eoff[pss] = (m < M && co < a.K) ? pix * (unsigned)a.K + (unsigned)co : ~0u;   // output < 2^31 elements (host check)
     }
     const bool epi_on = MODE == 0 && a.epi != 0;
-    const bool epi_dgrad_stats = MODE == 1 && a.epi == 4;       // dgrad + reduction pass of the next BatchNorm backward
+    const bool epi_dgrad_stats = MODE != 0 && a.epi == 4;       // dgrad + reduction pass of the next BatchNorm backward
     const void* pre_src = (epi_on || epi_dgrad_stats) ? a.ep_src : a.addend;
     const unsigned char* pre_msk = epi_on ? (a.epi == 1 ? nullptr : a.ep_mask_in) : epi_dgrad_stats ? a.ep_mask_in : a.addend_mask;
     u32x4 pre[NPASS];
@@ -554,7 +554,8 @@ __global__ __launch_bounds__(256, igemm_waves_per_simd(WP, ONE, STG)) void conv_
     }
     if (yg == nullptr) return;          // statistics-only pass
 
-    // epi 4 (dgrad, stride 1): besides writing the tile g = dL/d(activation), accumulate what the BatchNorm in front
+    // epi 4 (dgrad; the parity classes of a strided dgrad partition the output, so every element is seen once):
+    // besides writing the tile g = dL/d(activation), accumulate what the BatchNorm in front
     // of that activation needs for ITS backward - sum(g'), sum(g' * c) with g' = g under the ReLU bit mask
     // ep_mask_in and c = ep_src the BatchNorm's raw input - so no separate reduction pass re-reads g.
     if (epi_dgrad_stats) {

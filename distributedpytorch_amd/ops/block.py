@@ -61,14 +61,14 @@ _DGRAD_BN_STATS = os.environ.get("DPA_NO_DGRAD_BN_STATS", "0") != "1"
 
 def _dgrad_then_bn_bwd(C, conv, bn, dy, hw, mask, x_raw, mean, invstd, grads, slot):
     """``da = dgrad(conv, dy)`` followed by the backward of the BatchNorm (+ReLU) whose output ``da`` is the gradient
-    of.  At stride 1 the dgrad kernel's epilogue also produces that BatchNorm's reduction pass (sum g', sum g' * x
+    of.  The dgrad kernel's epilogue also produces that BatchNorm's reduction pass (sum g', sum g' * x
     from the tile it is about to write), so the stand-alone statistics kernel - one full read of ``da`` and of the
     BatchNorm input - is skipped: finalize + apply only."""
     tg, tb = _sink.target(bn.weight), _sink.target(bn.bias)
     sunk = tg is not None and tb is not None
-    if _DGRAD_BN_STATS and conv.stride == 1:
+    if _DGRAD_BN_STATS:
         sb = bn.stats_buffer_bwd(dy.device)
-        da = C.conv_dgrad(dy, _wt(C, conv), hw[0], hw[1], 1, conv.padding, None, None, x_raw, mask, sb)
+        da = C.conv_dgrad(dy, _wt(C, conv), hw[0], hw[1], conv.stride, conv.padding, None, None, x_raw, mask, sb)
         co = C.bn_bwd_coefs(sb, da.numel() // da.shape[-1], bn.weight.detach(), mean, invstd,
                             tg if sunk else None, tb if sunk else None)
         if sunk:

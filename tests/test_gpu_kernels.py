@@ -410,12 +410,14 @@ def test_fused_bn_relu_maxpool_matches_unfused_ops(shape):
     _close(dx, dx_ref.float(), 2e-2, 3e-2, "dx", max_bad_frac=1e-3)
 
 
-@pytest.mark.parametrize("case", [(2, 14, 14, 128, 64, 1, 0), (2, 14, 14, 64, 64, 3, 1), (3, 9, 11, 256, 136, 1, 0)])
+@pytest.mark.parametrize("case", [(2, 14, 14, 128, 64, 1, 0, 1), (2, 14, 14, 64, 64, 3, 1, 1), (3, 9, 11, 256, 136, 1, 0, 1),
+                                  (2, 14, 14, 64, 128, 3, 1, 2), (2, 15, 13, 128, 64, 1, 0, 2)])
 def test_dgrad_with_fused_bn_backward_statistics(case):
     """conv_dgrad(..., bn_x, bn_mask, bn_stats) + bn_bwd_coefs + bn_bwd_apply == conv_dgrad + bn_backward."""
-    N, H, W, K, Cc, R, pad = case                     # dy has K channels, the gradient da / BatchNorm has Cc
+    N, H, W, K, Cc, R, pad, st = case                 # dy has K channels, the gradient da / BatchNorm has Cc
     C_ = _C()
-    dy = _rand_bf16(N, H, W, K, scale=0.1, seed=41)
+    Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
+    dy = _rand_bf16(N, Ho, Wo, K, scale=0.1, seed=41)
     w = _rand_bf16(K, R, R, Cc, scale=0.1, seed=42)
     wt = C_.transpose_filter(w)
     x = _rand_bf16(N, H, W, Cc, seed=43)              # the BatchNorm's raw input
@@ -424,10 +426,10 @@ def test_dgrad_with_fused_bn_backward_statistics(case):
     mean = xf.mean((0, 1, 2)); invstd = torch.rsqrt(xf.var((0, 1, 2), unbiased=False) + 1e-5)
     bits = torch.rand(N, H, W, Cc, generator=torch.Generator().manual_seed(44)) > 0.4
     mask = (bits.view(-1, 8).to(torch.uint8) << torch.arange(8, dtype=torch.uint8)).sum(1).to(torch.uint8).to(DEV)
-    da_ref = C_.conv_dgrad(dy, wt, H, W, 1, pad, None, None)
+    da_ref = C_.conv_dgrad(dy, wt, H, W, st, pad, None, None)
     dx_ref, dg_ref, db_ref = C_.bn_backward(da_ref, mask, x, gamma, mean, invstd, True, None, None, None)
     sb = torch.zeros(32, 2, Cc, device=DEV)
-    da = C_.conv_dgrad(dy, wt, H, W, 1, pad, None, None, x, mask, sb)
+    da = C_.conv_dgrad(dy, wt, H, W, st, pad, None, None, x, mask, sb)
     assert torch.equal(da, da_ref)
     co = C_.bn_bwd_coefs(sb, N * H * W, gamma, mean, invstd, None, None)
     assert float(sb.abs().max()) == 0.0
