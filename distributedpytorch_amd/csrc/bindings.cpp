@@ -179,8 +179,8 @@ Tensor bn_bwd_coefs(Tensor& stats_buf, int64_t P, const Tensor& gamma, const Ten
 }
 
 // dgrad: dy [N,Ho,Wo,K] bf16, wt [C,R,S,K] bf16 (filter with K and C swapped) -> dx [N,H,W,C]
-// Optional bn_x / bn_mask / bn_stats (no addend): the kernel also adds sum(g'), sum(g' * bn_x) per channel
-// into bn_stats ([rows,2,C] fp32, zeroed), g' = dx under the ReLU bit mask bn_mask - the reduction pass of the
+// Optional bn_x / bn_mask / bn_stats: the kernel also adds sum(g'), sum(g' * bn_x) per channel
+// into bn_stats ([rows,2,C] fp32, zeroed), g' = dx (addend included) under the ReLU bit mask bn_mask - the reduction pass of the
 // backward of the BatchNorm whose output this dx is the gradient of (finish with bn_bwd_coefs + bn_bwd_apply).
 Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int64_t stride, int64_t pad,
                   const c10::optional<Tensor>& addend, const c10::optional<Tensor>& addend_mask,
@@ -212,7 +212,6 @@ Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int6
     a.N = N; a.H = Ho; a.W = Wo; a.C = K; a.K = C; a.R = R; a.S = S; a.Ho = H; a.Wo = W;
     a.stride = stride; a.pad = pad; a.mode = 1; a.act = 0;
     if (bn_x.has_value() && bn_x->defined()) {
-        TORCH_CHECK(a.addend == nullptr, "conv_dgrad: fused BatchNorm statistics cannot be combined with an addend");
         TORCH_CHECK(bn_mask.has_value() && bn_mask->defined() && bn_stats.has_value() && bn_stats->defined(), "conv_dgrad: bn_mask / bn_stats missing");
         CHECK_BF16((*bn_x)); CHECK_F32((*bn_stats));
         TORCH_CHECK(bn_x->numel() == dx.numel() && bn_mask->scalar_type() == at::kByte && bn_mask->is_contiguous() &&

@@ -408,8 +408,8 @@ __global__ __launch_bounds__(256, igemm_waves_per_simd(WP, ONE, STG)) void conv_
     }
     const bool epi_on = MODE == 0 && a.epi != 0;
     const bool epi_dgrad_stats = MODE != 0 && a.epi == 4;       // dgrad + reduction pass of the next BatchNorm backward
-    const void* pre_src = (epi_on || epi_dgrad_stats) ? a.ep_src : a.addend;
-    const unsigned char* pre_msk = epi_on ? (a.epi == 1 ? nullptr : a.ep_mask_in) : epi_dgrad_stats ? a.ep_mask_in : a.addend_mask;
+    const void* pre_src = epi_on ? a.ep_src : a.addend;
+    const unsigned char* pre_msk = epi_on ? (a.epi == 1 ? nullptr : a.ep_mask_in) : a.addend_mask;
     u32x4 pre[NPASS];
     unsigned pmk[NPASS];
     if (pre_src != nullptr) {
@@ -559,6 +559,18 @@ __global__ __launch_bounds__(256, igemm_waves_per_simd(WP, ONE, STG)) void conv_
     // of that activation needs for ITS backward - sum(g'), sum(g' * c) with g' = g under the ReLU bit mask
     // ep_mask_in and c = ep_src the BatchNorm's raw input - so no separate reduction pass re-reads g.
     if (epi_dgrad_stats) {
+        // the BatchNorm input and its ReLU bits for this thread's 8 passes (the accumulators are in LDS by now, their
+        // registers free); the addend operands, when present, were issued before the staging barrier
+        const unsigned ybytes = (unsigned)a.N * a.Ho * a.Wo * a.K * 2u;
+        const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)a.ep_src, 0, ybytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)a.ep_mask_in, 0, ybytes >> 4, 0x00020000);
+        u32x4 cx[NPASS];
+        unsigned kx[NPASS];
+#pragma unroll
+        for (int pss = 0; pss < NPASS; ++pss) {
+            cx[pss] = __builtin_amdgcn_raw_buffer_load_b128(crs, eoff[pss] != ~0u ? eoff[pss] * 2u : 0xFFFFFFF0u, 0, 0);
+            kx[pss] = __builtin_amdgcn_raw_buffer_load_b8(krs, eoff[pss] != ~0u ? eoff[pss] >> 3 : 0xFFFFFFF0u, 0, 0);
+        }
         float s8[8], q8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s8[j] = 0.f; q8[j] = 0.f; }
@@ -566,11 +578,21 @@ __global__ __launch_bounds__(256, igemm_waves_per_simd(WP, ONE, STG)) void conv_
         for (int pss = 0; pss < NPASS; ++pss) {
             const int row = pss * RPP + orow;
             if (eoff[pss] != ~0u) {
-                const uint4 v = *(const uint4*)(cs + row * CS + och * 8);
-                *(uint4*)(yg + (size_t)eoff[pss]) = v;
+                uint4 v = *(const uint4*)(cs + row * CS + och * 8);
                 float g[8], c[8];
-                unpack8(v, g); unpack8(__builtin_bit_cast(uint4, pre[pss]), c);
-                const unsigned mk = pmk[pss];
+                unpack8(v, g);
+                if (pre_src != nullptr) {                  // residual / shortcut gradient joins first (as in the plain write-out)
+                    float ad[8];
+                    unpack8(__builtin_bit_cast(uint4, pre[pss]), ad);
+                    const unsigned am = pmk[pss];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] += ((am >> j) & 1u) ? ad[j] : 0.f;
+                    v = pack8(g);
+                    unpack8(v, g);                         // statistics of the bf16 values that are stored
+                }
+                *(uint4*)(yg + (size_t)eoff[pss]) = v;
+                unpack8(__builtin_bit_cast(uint4, cx[pss]), c);
+                const unsigned mk = kx[pss];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float gm = ((mk >> j) & 1u) ? g[j] : 0.f;

@@ -57,6 +57,7 @@ def _bn_bwd(C, bn, dy, mask, x_raw, mean, invstd, relu, grads, slot):
 
 
 _DGRAD_BN_STATS = os.environ.get("DPA_NO_DGRAD_BN_STATS", "0") != "1"
+_CROSS_BN3 = _DGRAD_BN_STATS and os.environ.get("DPA_NO_CROSS_BN3", "0") != "1"
 
 
 def _dgrad_then_bn_bwd(C, conv, bn, dy, hw, mask, x_raw, mean, invstd, grads, slot):
@@ -106,9 +107,10 @@ def _wgrad(C, conv, x, dy, grads, slot, in_line=False):
 
 class _BottleneckFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, blk, *params):
+    def forward(ctx, x, blk, prev, *params):
         C = _ext.load()
         ds = blk.downsample is not None
+        ctx.prev = prev                 # the bottleneck whose output x is (or None): see _CROSS_BN3 below
         ds_done = None
         if ds and _DS_SIDE and _side.active(x):
             # the projection shortcut is independent of conv1 -> conv2: it runs on the side stream beside them
@@ -144,6 +146,9 @@ class _BottleneckFn(torch.autograd.Function):
             saved += [cd, md, isd]
         ctx.save_for_backward(*saved)
         ctx.blk = blk
+        # what the NEXT block's backward needs to fold this block's bn3 reduction pass into its last dgrad
+        blk._bn3_saved = None if recompute else (c3, k3)
+        blk._bn3_stats_for = None
         return out
 
     @staticmethod
@@ -185,8 +190,26 @@ class _BottleneckFn(torch.autograd.Function):
             else:
                 grads[7], grads[8] = co[0], co[1]
             d3 = C.conv_bnb_apply(a2, w3, 1, 0, dout, k3, co[2], co[3], co[4])
+        elif getattr(blk, "_bn3_stats_for", None) is not None:
+            # the block after this one already accumulated bn3's reduction pass while writing dout (_CROSS_BN3)
+            sb = blk.bn3.stats_buffer_bwd(dout.device)
+            if blk._bn3_stats_for == (dout.data_ptr(), tuple(dout.shape)):
+                tg, tb = _sink.target(blk.bn3.weight), _sink.target(blk.bn3.bias)
+                sunk = tg is not None and tb is not None
+                co = C.bn_bwd_coefs(sb, dout.numel() // dout.shape[-1], blk.bn3.weight.detach(), m3, i3,
+                                    tg if sunk else None, tb if sunk else None)
+                if sunk:
+                    _sink.ready(blk.bn3.weight); _sink.ready(blk.bn3.bias)
+                else:
+                    grads[7], grads[8] = co[0], co[1]
+                d3 = C.bn_bwd_apply(dout, k3, c3, co, True)
+            else:                       # dout is not the tensor those statistics were taken from (another consumer
+                sb.zero_()              # of the block output added its gradient): discard them
+                d3 = _bn_bwd(C, blk.bn3, dout, k3, c3, m3, i3, True, grads, 7)
+            blk._bn3_stats_for = None
         else:
             d3 = _bn_bwd(C, blk.bn3, dout, k3, c3, m3, i3, True, grads, 7)
+        blk._bn3_saved = None
         # each wgrad goes to the side stream BEFORE the dgrad that shares its operand is enqueued: the two GEMMs
         # run side by side and the wgrad's tail overlaps the next BatchNorm backward (measured better than
         # enqueueing it after the dgrad, and better than keeping the HBM-bound stage-1/2 1x1 wgrads in line)
@@ -197,9 +220,15 @@ class _BottleneckFn(torch.autograd.Function):
         _wgrad(C, blk.conv1, x, d1, grads, 0)
         dx = None
         need_dx = ctx.needs_input_grad[0]
+        # bn3 of the PREVIOUS block: its incoming gradient is the dx this block is about to write, so the reduction
+        # pass of its backward (sum g', sum g' * c3 under its ReLU bits) rides this dgrad's epilogue
+        prev, bn_args = ctx.prev, (None, None, None)
+        if (_CROSS_BN3 and need_dx and prev is not None and getattr(prev, "_bn3_saved", None) is not None
+                and prev._bn3_saved[0].shape == x.shape):
+            bn_args = (prev._bn3_saved[0], prev._bn3_saved[1], prev.bn3.stats_buffer_bwd(dout.device))
         if ds_done is not None:
             _side.wait(ds_done, ds_box)
-            dx = C.conv_dgrad(d1, _wt(C, blk.conv1), x.shape[1], x.shape[2], 1, 0, ds_box[0], None)
+            dx = C.conv_dgrad(d1, _wt(C, blk.conv1), x.shape[1], x.shape[2], 1, 0, ds_box[0], None, *bn_args)
         elif ds:
             cd, md, isd = sv[15:18]
             dconv = blk.downsample[0]
@@ -207,11 +236,13 @@ class _BottleneckFn(torch.autograd.Function):
             _wgrad(C, dconv, x, dd, grads, 9)
             if need_dx:
                 dxd = C.conv_dgrad(dd, _wt(C, dconv), x.shape[1], x.shape[2], dconv.stride, 0, None, None)
-                dx = C.conv_dgrad(d1, _wt(C, blk.conv1), x.shape[1], x.shape[2], 1, 0, dxd, None)
+                dx = C.conv_dgrad(d1, _wt(C, blk.conv1), x.shape[1], x.shape[2], 1, 0, dxd, None, *bn_args)
         elif need_dx:
             # identity shortcut: the masked residual gradient is added in the dgrad epilogue
-            dx = C.conv_dgrad(d1, _wt(C, blk.conv1), x.shape[1], x.shape[2], 1, 0, dout, k3)
-        return (dx, None, *grads)
+            dx = C.conv_dgrad(d1, _wt(C, blk.conv1), x.shape[1], x.shape[2], 1, 0, dout, k3, *bn_args)
+        if bn_args[0] is not None and dx is not None:
+            prev._bn3_stats_for = (dx.data_ptr(), tuple(dx.shape))
+        return (dx, None, None, *grads)
 
 
 def bottleneck_params(blk):
@@ -229,8 +260,11 @@ def can_fuse(blk, x: torch.Tensor) -> bool:
 
 
 def bottleneck(blk, x: torch.Tensor) -> torch.Tensor:
-    """Fused bottleneck block (GPU, training, bf16 shadows present)."""
-    return _BottleneckFn.apply(x, blk, *bottleneck_params(blk))
+    """Fused bottleneck block (GPU, training, bf16 shadows present).  Consecutive blocks are linked through a tensor
+    attribute so that a block's backward can serve the bn3 of the block before it (see _BottleneckFn.backward)."""
+    out = _BottleneckFn.apply(x, blk, getattr(x, "_dpa_producer", None), *bottleneck_params(blk))
+    out._dpa_producer = blk
+    return out
 
 
 # ---------------------------------------------------------------------------------------------- stem

@@ -102,6 +102,39 @@ def test_side_stream_wgrad_matches_in_line_wgrad():
     assert cos > 0.999 and ((a1 - b1).norm() / b1.norm()).item() < 0.05, cos
 
 
+def test_block_output_with_a_second_consumer_falls_back_to_standalone_bn3_statistics():
+    """The next block folds bn3's backward reduction into its last dgrad only if bn3's incoming gradient IS the
+    tensor that dgrad wrote.  With an auxiliary consumer of the block output autograd sums two gradients: the folded
+    statistics must be discarded (and the accumulator re-zeroed) - gradients equal the op-by-op path."""
+    from distributedpytorch_amd import ops
+    from distributedpytorch_amd.models import resnet
+    from distributedpytorch_amd.ops import block, sink
+    from distributedpytorch_amd.parallel.flat import FlatParams
+    x = torch.randn(8, 3, 64, 64, device=DEV); y = torch.randint(0, 16, (8,), device=DEV)
+    res = []
+    for enabled in (True, False):
+        torch.manual_seed(6)
+        m = resnet.tiny_resnet().to(DEV).train()
+        for mod in m.modules():
+            if hasattr(mod, "running_mean"):
+                torch.nn.init.uniform_(mod.weight, 0.5, 1.5); torch.nn.init.normal_(mod.bias, 0.0, 0.2)
+        flat = FlatParams(m)
+        flat.install_sink(None)
+        block.ENABLED = enabled
+        try:
+            for _ in range(2):                     # twice: a dirty accumulator would corrupt the second step
+                flat.grad.zero_()
+                y1 = m.block1(m.stem(x))
+                logits = m.head(m.block2(y1))
+                loss = ops.softmax_cross_entropy(logits, y, 16) + 0.05 * y1.float().square().mean()
+                loss.backward()
+        finally:
+            block.ENABLED = True
+            sink.uninstall()
+        res.append((float(loss.detach()), flat.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters()}))
+    _compare_paths(*res[0], *res[1])
+
+
 def _compare_paths(l1, g1, d1, l2, g2, d2):
     assert abs(l1 - l2) < 1e-3
     # The BN statistics are summed with fp32 atomics (order varies run to run), so an activation
