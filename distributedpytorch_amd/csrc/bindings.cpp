@@ -28,8 +28,10 @@ struct Guard {
 
 // ---------------------------------------------------------------- conv
 // x [N,H,W,C] bf16, w [K,R,S,C] bf16 -> y [N,Ho,Wo,K] bf16 (+ optional BN partial stats [rows,2,K])
+// `addend` (bf16, the output's shape): y = conv(x) + bias + addend - a residual connection in the GEMM epilogue.
 std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias, int64_t stride,
-                               int64_t pad, int64_t act, bool want_stats, const c10::optional<Tensor>& stats_buf) {
+                               int64_t pad, int64_t act, bool want_stats, const c10::optional<Tensor>& stats_buf,
+                               const c10::optional<Tensor>& addend) {
     CHECK_BF16(x); CHECK_BF16(w);
     TORCH_CHECK(x.dim() == 4 && w.dim() == 4, "conv_fprop: x and w must be 4-D (NHWC / KRSC)");
     const int64_t N = x.size(0), H = x.size(1), W = x.size(2), C = x.size(3);
@@ -66,6 +68,11 @@ std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::opti
         }
         a.stats = stats.data_ptr<float>();
         a.stats_rows = stats.size(0);
+    }
+    if (addend.has_value() && addend->defined()) {
+        CHECK_BF16((*addend));
+        TORCH_CHECK(addend->numel() == y.numel() && !want_stats && act == 0, "conv_fprop: addend must match the output; no stats / activation with it");
+        a.addend = addend->data_ptr();
     }
     a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.Ho = Ho; a.Wo = Wo;
     a.stride = stride; a.pad = pad; a.mode = 0; a.act = act;
@@ -756,7 +763,8 @@ void bind_rccl(pybind11::module_& m);         // rccl_comm.cpp
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "distributedpytorch_amd gfx950 kernels";
-    m.def("conv_fprop", &conv_fprop);
+    m.def("conv_fprop", &conv_fprop, py::arg("x"), py::arg("w"), py::arg("bias"), py::arg("stride"), py::arg("pad"), py::arg("act"),
+          py::arg("want_stats"), py::arg("stats_buf"), py::arg("addend") = py::none());
     m.def("conv_dgrad", &conv_dgrad, py::arg("dy"), py::arg("wt"), py::arg("H"), py::arg("W"), py::arg("stride"), py::arg("pad"),
           py::arg("addend"), py::arg("addend_mask"), py::arg("bn_x") = py::none(), py::arg("bn_mask") = py::none(),
           py::arg("bn_stats") = py::none());

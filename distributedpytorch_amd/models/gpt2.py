@@ -41,8 +41,8 @@ class Attention(nn.Module):
         self.c_attn = Linear(cfg.n_embd, 3 * cfg.n_embd, init_std=0.02)
         self.c_proj = Linear(cfg.n_embd, cfg.n_embd, init_std=0.02 / math.sqrt(2 * cfg.n_layer))
 
-    def forward(self, x):
-        return self.c_proj(ops.causal_attention(self.c_attn(x), self.n_head))
+    def forward(self, x, residual=None):
+        return self.c_proj(ops.causal_attention(self.c_attn(x), self.n_head), residual=residual)
 
 
 class MLP(nn.Module):
@@ -51,8 +51,8 @@ class MLP(nn.Module):
         self.c_fc = Linear(cfg.n_embd, 4 * cfg.n_embd, init_std=0.02)
         self.c_proj = Linear(4 * cfg.n_embd, cfg.n_embd, init_std=0.02 / math.sqrt(2 * cfg.n_layer))
 
-    def forward(self, x):
-        return self.c_proj(ops.gelu(self.c_fc(x)))
+    def forward(self, x, residual=None):
+        return self.c_proj(ops.gelu(self.c_fc(x)), residual=residual)
 
 
 class Block(nn.Module):
@@ -64,8 +64,8 @@ class Block(nn.Module):
         self.mlp = MLP(cfg)
 
     def forward(self, x):
-        x = ops.add(x, self.attn(self.ln_1(x)))
-        return ops.add(x, self.mlp(self.ln_2(x)))
+        x = self.attn(self.ln_1(x), residual=x)          # the residual adds ride the projection GEMMs' epilogues
+        return self.mlp(self.ln_2(x), residual=x)
 
 
 class Embedding(nn.Module):

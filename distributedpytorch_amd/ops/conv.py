@@ -33,10 +33,12 @@ def _lp(weight: torch.Tensor, weight_lp: Optional[torch.Tensor]) -> torch.Tensor
 
 class _ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, weight_lp, bias, stride, pad, want_stats, act, wshape, stats_buf=None, weight_lp_t=None):
+    def forward(ctx, x, weight, weight_lp, bias, stride, pad, want_stats, act, wshape, stats_buf=None, weight_lp_t=None,
+                residual=None):
         C = _ext.load()
         w = _lp(weight, weight_lp).view(wshape)   # KRSC view (a Linear weight [out,in] is K,1,1,C)
-        outs = C.conv_fprop(x, w, bias, stride, pad, act, want_stats, stats_buf)
+        outs = C.conv_fprop(x, w, bias, stride, pad, act, want_stats, stats_buf, residual)   # + residual in the epilogue
+        ctx.has_residual = residual is not None
         ctx.save_for_backward(x, w)
         ctx.weight = weight
         ctx.bias = bias
@@ -82,7 +84,9 @@ class _ConvFn(torch.autograd.Function):
             C.colsum(dy, db_tgt)
         if db_tgt is not None and db is None:
             _sink.ready(bias)
-        return dx, dw, None, db, None, None, None, None, None, None, None
+        # the residual connection passes the gradient through unchanged
+        dres = dy if (ctx.has_residual and ctx.needs_input_grad[11]) else None
+        return dx, dw, None, db, None, None, None, None, None, None, None, dres
 
 
 def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, weight_lp: Optional[torch.Tensor] = None,
@@ -104,14 +108,18 @@ def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, weight_lp: Optional[torch
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, weight_lp: Optional[torch.Tensor] = None,
-           bias: Optional[torch.Tensor] = None, weight_lp_t: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``y = x @ weight^T + bias`` with ``weight [out, in]``; any leading dims on ``x``.
-    ``weight_lp_t`` is the optional bf16 ``[in, out]`` twin the input gradient multiplies by."""
+           bias: Optional[torch.Tensor] = None, weight_lp_t: Optional[torch.Tensor] = None,
+           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``y = x @ weight^T + bias (+ residual)`` with ``weight [out, in]``; any leading dims on ``x``.
+    ``weight_lp_t`` is the optional bf16 ``[in, out]`` twin the input gradient multiplies by; ``residual`` (the
+    output's shape) is added in the GEMM epilogue."""
     if _ext.use_hip(x):
         lead = x.shape[:-1]
         cin, cout = weight.shape[1], weight.shape[0]
         x4 = x.reshape(-1, 1, 1, cin)
         wt = None if weight_lp_t is None else weight_lp_t.view(cin, 1, 1, cout)
-        y, _ = _ConvFn.apply(x4, weight, weight_lp, bias, 1, 0, False, 0, (cout, 1, 1, cin), None, wt)
+        r4 = None if residual is None else residual.contiguous().reshape(-1, 1, 1, cout)
+        y, _ = _ConvFn.apply(x4, weight, weight_lp, bias, 1, 0, False, 0, (cout, 1, 1, cin), None, wt, r4)
         return y.reshape(*lead, cout)
-    return F.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
+    y = F.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
+    return y if residual is None else y + residual
