@@ -31,8 +31,10 @@ std::vector<Tensor> layernorm_fwd(const Tensor& x, const Tensor& g, const Tensor
 
 // returns (dx bf16, dgamma fp32 [C], dbeta fp32 [C]); with dgamma_acc / dbeta_acc (fp32 [C], e.g. slices of the
 // flat gradient buffer) the parameter gradients are ADDED there instead and the two returned tensors are empty
+// `addend` (bf16, x's shape): dx += addend - the gradient of the residual connection that forks off in front of the LayerNorm
 std::vector<Tensor> layernorm_bwd(const Tensor& dy, const Tensor& x, const Tensor& g, const Tensor& mean, const Tensor& rstd,
-                                  const c10::optional<Tensor>& dgamma_acc, const c10::optional<Tensor>& dbeta_acc) {
+                                  const c10::optional<Tensor>& dgamma_acc, const c10::optional<Tensor>& dbeta_acc,
+                                  const c10::optional<Tensor>& addend) {
     CHECK_BF16(dy); CHECK_BF16(x); CHECK_F32(g); CHECK_F32(mean); CHECK_F32(rstd);
     const int64_t C = x.size(-1), rows = x.numel() / C;
     TORCH_CHECK(dy.numel() == x.numel() && C % 8 == 0 && C <= 2048 && g.numel() == C && mean.numel() == rows && rstd.numel() == rows,
@@ -42,8 +44,14 @@ std::vector<Tensor> layernorm_bwd(const Tensor& dy, const Tensor& x, const Tenso
     const int pr = dpa::layernorm_partial_rows(rows);
     Tensor dx = torch::empty_like(x), part = torch::empty({2, pr, C}, fopt);
     float* pp = part.data_ptr<float>();
+    const void* ad = nullptr;
+    if (addend.has_value() && addend->defined()) {
+        CHECK_BF16((*addend));
+        TORCH_CHECK(addend->numel() == x.numel(), "layernorm_bwd: addend shape");
+        ad = addend->data_ptr();
+    }
     dpa::layernorm_bwd(dy.data_ptr(), x.data_ptr(), g.data_ptr<float>(), mean.data_ptr<float>(), rstd.data_ptr<float>(),
-                       dx.data_ptr(), pp, pp + (long)pr * C, pr, rows, C, cur_stream());
+                       dx.data_ptr(), pp, pp + (long)pr * C, pr, rows, C, ad, cur_stream());
     const bool acc = dgamma_acc.has_value() && dgamma_acc->defined() && dbeta_acc.has_value() && dbeta_acc->defined();
     if (acc) {
         CHECK_F32((*dgamma_acc)); CHECK_F32((*dbeta_acc));
@@ -110,7 +118,8 @@ Tensor attention_bwd(const Tensor& qkv, const Tensor& out, const Tensor& dout, c
 
 void bind_transformer(pybind11::module_& m) {
     m.def("layernorm_fwd", &layernorm_fwd);
-    m.def("layernorm_bwd", &layernorm_bwd);
+    m.def("layernorm_bwd", &layernorm_bwd, pybind11::arg("dy"), pybind11::arg("x"), pybind11::arg("g"), pybind11::arg("mean"),
+          pybind11::arg("rstd"), pybind11::arg("dgamma_acc"), pybind11::arg("dbeta_acc"), pybind11::arg("addend") = pybind11::none());
     m.def("embedding_fwd", &embedding_fwd);
     m.def("embedding_bwd", &embedding_bwd);
 #ifdef DPA_HAVE_ATTENTION

@@ -144,7 +144,8 @@ void scale_f32(float* x, long n, float s, hipStream_t st);
 void layernorm_fwd(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd,
                    long rows, int C, float eps, hipStream_t st);
 void layernorm_bwd(const void* dy, const void* x, const float* g, const float* mean, const float* rstd,
-                   void* dx, float* dg_partial, float* db_partial, int partial_rows, long rows, int C, hipStream_t st);
+                   void* dx, float* dg_partial, float* db_partial, int partial_rows, long rows, int C,
+                   const void* addend /* bf16 [rows, C] added to dx, or nullptr */, hipStream_t st);
 int layernorm_partial_rows(long rows);
 void reduce_partials(const float* partial, int rows, int C, float* out, int accumulate, hipStream_t st);
 // partial = [2][rows][C]: both halves folded by one launch into out_a / out_b

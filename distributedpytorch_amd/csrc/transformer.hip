@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
                                                             const float* __restrict__ g, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, unsigned short* __restrict__ dx,
                                                             float* __restrict__ dg_part, float* __restrict__ db_part,
-                                                            long rows, int C) {
+                                                            long rows, int C, const unsigned short* __restrict__ addend) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = C / 8;
     float dg[NCH][8], db[NCH][8];
@@ -93,6 +93,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
                 float o[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = rs * (gy[k][j] - s1 - xh[k][j] * s2);
+                if (addend != nullptr) {           // gradient arriving over the residual connection around this LayerNorm
+                    float ad[8];
+                    { const uint4 u = *(const uint4*)(addend + row * C + ch * 8); unpack8(u, ad); }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] += ad[j];
+                }
                 *(uint4*)(dx + row * C + ch * 8) = pack8(o);
             }
         }
@@ -213,9 +219,11 @@ void layernorm_fwd(const void* x, const float* g, const float* b, void* y, float
 }
 
 void layernorm_bwd(const void* dy, const void* x, const float* g, const float* mean, const float* rstd,
-                   void* dx, float* dg_partial, float* db_partial, int partial_rows, long rows, int C, hipStream_t st) {
+                   void* dx, float* dg_partial, float* db_partial, int partial_rows, long rows, int C, const void* addend,
+                   hipStream_t st) {
 #define DPA_LN_BWD(NCH_) hipLaunchKernelGGL(layernorm_bwd_kernel<NCH_>, dim3(partial_rows), dim3(256), 0, st, \
-        (const unsigned short*)dy, (const unsigned short*)x, g, mean, rstd, (unsigned short*)dx, dg_partial, db_partial, rows, C)
+        (const unsigned short*)dy, (const unsigned short*)x, g, mean, rstd, (unsigned short*)dx, dg_partial, db_partial, rows, C, \
+        (const unsigned short*)addend)
     if (C <= 512) DPA_LN_BWD(1); else if (C <= 1024) DPA_LN_BWD(2); else DPA_LN_BWD(4);
 #undef DPA_LN_BWD
 }

@@ -64,8 +64,12 @@ class Block(nn.Module):
         self.mlp = MLP(cfg)
 
     def forward(self, x):
-        x = self.attn(self.ln_1(x), residual=x)          # the residual adds ride the projection GEMMs' epilogues
-        return self.mlp(self.ln_2(x), residual=x)
+        # pre-norm residual blocks: the forward add rides the projection GEMM's epilogue, the backward add of the
+        # residual-path gradient rides the LayerNorm-backward kernel (LayerNorm.fork)
+        x, h = self.ln_1.fork(x)
+        x = self.attn(h, residual=x)
+        x, h = self.ln_2.fork(x)
+        return self.mlp(h, residual=x)
 
 
 class Embedding(nn.Module):

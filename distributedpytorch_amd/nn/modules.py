@@ -134,3 +134,7 @@ class LayerNorm(nn.Module):
 
     def forward(self, x):
         return ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+    def fork(self, x):
+        """``(x, self(x))``; use the returned x for the residual connection around the normalised branch."""
+        return ops.layer_norm_fork(x, self.weight, self.bias, self.eps)

@@ -120,6 +120,44 @@ class _LayerNormFn(torch.autograd.Function):
         return dx, dg, db, None
 
 
+class _LayerNormForkFn(torch.autograd.Function):
+    """``(x, LayerNorm(x))``: the pre-norm residual block's fork.  The first output IS the input; routing it through
+    this node lets backward add the gradient that arrives over the residual connection inside the LayerNorm-backward
+    kernel instead of in a separate elementwise pass."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        C = _ext.load()
+        y, mean, rstd = C.layernorm_fwd(x, gamma.detach(), beta.detach(), eps)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.gamma, ctx.beta = gamma, beta
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        C = _ext.load()
+        x, mean, rstd = ctx.saved_tensors
+        tg, tb = _sink.target(ctx.gamma), _sink.target(ctx.beta)
+        ad = None if dres is None else dres.contiguous()
+        if dy is None:                      # the normalised branch was not used
+            return dres, None, None, None
+        if tg is not None and tb is not None:
+            dx, _, _ = C.layernorm_bwd(dy.contiguous(), x, ctx.gamma.detach(), mean, rstd, tg, tb, ad)
+            _sink.ready(ctx.gamma); _sink.ready(ctx.beta)
+            return dx, None, None, None
+        dx, dg, db = C.layernorm_bwd(dy.contiguous(), x, ctx.gamma.detach(), mean, rstd, None, None, ad)
+        dg = _grad_out(ctx.gamma, dg) if ctx.gamma.requires_grad else None
+        db = _grad_out(ctx.beta, db) if ctx.beta.requires_grad else None
+        return dx, dg, db, None
+
+
+def layer_norm_fork(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5):
+    """``(x, layer_norm(x))`` for ``x + f(layer_norm(x))`` blocks: use the returned x for the residual connection."""
+    if _ext.use_hip(x):
+        return _LayerNormForkFn.apply(x.contiguous(), gamma, beta, eps)
+    return x, F.layer_norm(x.float(), (x.shape[-1],), gamma, beta, eps).to(x.dtype)
+
+
 def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     if _ext.use_hip(x):
         return _LayerNormFn.apply(x.contiguous(), gamma, beta, eps)
