@@ -189,9 +189,12 @@ Tensor bn_bwd_coefs(Tensor& stats_buf, int64_t P, const Tensor& gamma, const Ten
 // Optional bn_x / bn_mask / bn_stats: the kernel also adds sum(g'), sum(g' * bn_x) per channel
 // into bn_stats ([rows,2,C] fp32, zeroed), g' = dx (addend included) under the ReLU bit mask bn_mask - the reduction pass of the
 // backward of the BatchNorm whose output this dx is the gradient of (finish with bn_bwd_coefs + bn_bwd_apply).
+// Optional gelu_x (bf16, dx's shape; stride 1, nothing else fused): dx = dgrad * gelu'(gelu_x) - the backward of a
+// tanh-GELU in front of this layer, in the epilogue.
 Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int64_t stride, int64_t pad,
                   const c10::optional<Tensor>& addend, const c10::optional<Tensor>& addend_mask,
-                  const c10::optional<Tensor>& bn_x, const c10::optional<Tensor>& bn_mask, const c10::optional<Tensor>& bn_stats) {
+                  const c10::optional<Tensor>& bn_x, const c10::optional<Tensor>& bn_mask, const c10::optional<Tensor>& bn_stats,
+                  const c10::optional<Tensor>& gelu_x) {
     CHECK_BF16(dy); CHECK_BF16(wt);
     TORCH_CHECK(dy.dim() == 4 && wt.dim() == 4, "conv_dgrad: 4-D tensors expected");
     const int64_t N = dy.size(0), Ho = dy.size(1), Wo = dy.size(2), K = dy.size(3);
@@ -226,6 +229,12 @@ Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int6
         TORCH_CHECK(bn_stats->dim() == 3 && bn_stats->size(1) == 2 && bn_stats->size(2) == C, "conv_dgrad: bn_stats must be [rows,2,C]");
         a.epi = 4; a.ep_src = bn_x->data_ptr(); a.ep_mask_in = bn_mask->data_ptr<uint8_t>();
         a.ep_stats = bn_stats->data_ptr<float>(); a.ep_stats_rows = (int)bn_stats->size(0);
+    }
+    if (gelu_x.has_value() && gelu_x->defined()) {
+        CHECK_BF16((*gelu_x));
+        TORCH_CHECK(stride == 1 && a.addend == nullptr && a.epi == 0 && gelu_x->numel() == dx.numel(),
+                    "conv_dgrad: gelu_x needs stride 1, dx's shape and no other fused epilogue");
+        a.epi = 5; a.ep_src = gelu_x->data_ptr();
     }
     dpa::conv_igemm(a, cur_stream());
     return dx;
@@ -767,7 +776,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("want_stats"), py::arg("stats_buf"), py::arg("addend") = py::none());
     m.def("conv_dgrad", &conv_dgrad, py::arg("dy"), py::arg("wt"), py::arg("H"), py::arg("W"), py::arg("stride"), py::arg("pad"),
           py::arg("addend"), py::arg("addend_mask"), py::arg("bn_x") = py::none(), py::arg("bn_mask") = py::none(),
-          py::arg("bn_stats") = py::none());
+          py::arg("bn_stats") = py::none(), py::arg("gelu_x") = py::none());
     m.def("bn_bwd_apply", &bn_bwd_apply);
     m.def("conv_fprop_stats", &conv_fprop_stats);
     m.def("conv_bn_res_relu", &conv_bn_res_relu);

@@ -101,6 +101,17 @@ __device__ __forceinline__ u32x4 buffer_words(const void* ptr, unsigned bytes) {
 // s_waitcnt immediate that waits for vmcnt <= n only (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14])
 constexpr int waitcnt_vm_only(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }
 
+// d/dx of the tanh-approximated GELU with tanh from one v_exp_f32 + one v_rcp_f32 (for GEMM epilogues, where the
+// libm tanhf expansion would outweigh the tile's main loop); error << one bf16 ulp of the product it scales
+__device__ __forceinline__ float gelu_tanh_grad_fast(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float x2 = x * x;
+    const float u = k0 * (x + k1 * x * x2);
+    const float e = __builtin_amdgcn_exp2f(fminf(u * 2.885390081777927f, 80.f));      // e^(2u), clamped (tanh -> 1)
+    const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+    return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * k0 * (1.f + 3.f * k1 * x2);
+}
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace dpa

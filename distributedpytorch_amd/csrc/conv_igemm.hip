@@ -408,7 +408,8 @@ __global__ __launch_bounds__(256, igemm_waves_per_simd(WP, ONE, STG)) void conv_
     }
     const bool epi_on = MODE == 0 && a.epi != 0;
     const bool epi_dgrad_stats = MODE != 0 && a.epi == 4;       // dgrad + reduction pass of the next BatchNorm backward
-    const void* pre_src = epi_on ? a.ep_src : a.addend;
+    const bool epi_gelu_bwd = MODE == 1 && a.epi == 5;          // dgrad through a GELU: y = tile * gelu'(ep_src)
+    const void* pre_src = (epi_on || epi_gelu_bwd) ? a.ep_src : a.addend;
     const unsigned char* pre_msk = epi_on ? (a.epi == 1 ? nullptr : a.ep_mask_in) : a.addend_mask;
     u32x4 pre[NPASS];
     unsigned pmk[NPASS];
@@ -609,7 +610,13 @@ __global__ __launch_bounds__(256, igemm_waves_per_simd(WP, ONE, STG)) void conv_
         const int row = pss * RPP + orow;
         if (eoff[pss] != ~0u) {
             uint4 v = *(const uint4*)(cs + row * CS + och * 8);
-            if (pre_src != nullptr) {
+            if (epi_gelu_bwd) {                    // g = the GELU's input: the activation's backward in the epilogue
+                float f[8], g[8];
+                unpack8(v, f); unpack8(__builtin_bit_cast(uint4, pre[pss]), g);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] *= gelu_tanh_grad_fast(g[j]);
+                v = pack8(f);
+            } else if (pre_src != nullptr) {
                 float f[8], g[8];
                 unpack8(v, f); unpack8(__builtin_bit_cast(uint4, pre[pss]), g);
                 const unsigned mk = pmk[pss];

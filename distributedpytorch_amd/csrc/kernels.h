@@ -41,6 +41,7 @@ struct ConvArgs {
     const unsigned char* ep_mask_in;
     unsigned char* ep_mask_out;
     float* ep_stats; int ep_stats_rows;
+    //   epi 5 (dgrad, stride 1): y = dgrad * gelu'(ep_src), ep_src = the input of the tanh-GELU in front of this layer
 };
 void conv_igemm(const ConvArgs& a, hipStream_t st);
 int conv_stats_rows(long M);  // replica rows of the stats buffer

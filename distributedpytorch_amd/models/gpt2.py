@@ -52,7 +52,7 @@ class MLP(nn.Module):
         self.c_proj = Linear(4 * cfg.n_embd, cfg.n_embd, init_std=0.02 / math.sqrt(2 * cfg.n_layer))
 
     def forward(self, x, residual=None):
-        return self.c_proj(ops.gelu(self.c_fc(x)), residual=residual)
+        return self.c_proj(self.c_fc(x), residual=residual, pre_gelu=True)     # gelu inside: its backward is an epilogue
 
 
 class Block(nn.Module):

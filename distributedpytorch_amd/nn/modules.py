@@ -116,10 +116,10 @@ class Linear(nn.Module):
         self.weight_lp: Optional[torch.Tensor] = None
         self.weight_lp_t: Optional[torch.Tensor] = None    # [in, out] twin for the input gradient, kept by FlatParams
 
-    def forward(self, x, keep_padding: bool = False, residual=None):
+    def forward(self, x, keep_padding: bool = False, residual=None, pre_gelu: bool = False):
         if residual is not None and self.out_padded != self.out_features:
-            return self.forward(x, keep_padding) + residual      # padded outputs: no fused residual
-        y = ops.linear(x, self.weight, self.weight_lp, self.bias, self.weight_lp_t, residual)
+            return self.forward(x, keep_padding, None, pre_gelu) + residual      # padded outputs: no fused residual
+        y = ops.linear(x, self.weight, self.weight_lp, self.bias, self.weight_lp_t, residual, pre_gelu)
         if not keep_padding and self.out_padded != self.out_features:
             y = y[..., : self.out_features]
         return y

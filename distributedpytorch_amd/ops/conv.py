@@ -34,9 +34,13 @@ def _lp(weight: torch.Tensor, weight_lp: Optional[torch.Tensor]) -> torch.Tensor
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, weight_lp, bias, stride, pad, want_stats, act, wshape, stats_buf=None, weight_lp_t=None,
-                residual=None):
+                residual=None, pre_gelu=False):
         C = _ext.load()
         w = _lp(weight, weight_lp).view(wshape)   # KRSC view (a Linear weight [out,in] is K,1,1,C)
+        ctx.pre_gelu = pre_gelu
+        if pre_gelu:                              # y = layer(gelu(x)): the GELU's backward rides the dgrad epilogue
+            ctx.gelu_in = x
+            x = C.ew2(x, x, 3)
         outs = C.conv_fprop(x, w, bias, stride, pad, act, want_stats, stats_buf, residual)   # + residual in the epilogue
         ctx.has_residual = residual is not None
         ctx.save_for_backward(x, w)
@@ -59,7 +63,8 @@ class _ConvFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wt = ctx.wt if ctx.wt is not None else C.transpose_filter(w)
-            dx = C.conv_dgrad(dy, wt, x.shape[1], x.shape[2], stride, pad, None, None)
+            dx = C.conv_dgrad(dy, wt, x.shape[1], x.shape[2], stride, pad, None, None, None, None, None,
+                              ctx.gelu_in if ctx.pre_gelu else None)
         weight, bias = ctx.weight, ctx.bias
         # bias gradient = column sums of dy: produced inside the wgrad kernel (one more MFMA against a tile of
         # ones) when a weight gradient is computed anyway, by the column-sum kernels otherwise
@@ -86,7 +91,7 @@ class _ConvFn(torch.autograd.Function):
             _sink.ready(bias)
         # the residual connection passes the gradient through unchanged
         dres = dy if (ctx.has_residual and ctx.needs_input_grad[11]) else None
-        return dx, dw, None, db, None, None, None, None, None, None, None, dres
+        return dx, dw, None, db, None, None, None, None, None, None, None, dres, None
 
 
 def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, weight_lp: Optional[torch.Tensor] = None,
@@ -109,17 +114,20 @@ def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, weight_lp: Optional[torch
 
 def linear(x: torch.Tensor, weight: torch.Tensor, weight_lp: Optional[torch.Tensor] = None,
            bias: Optional[torch.Tensor] = None, weight_lp_t: Optional[torch.Tensor] = None,
-           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+           residual: Optional[torch.Tensor] = None, pre_gelu: bool = False) -> torch.Tensor:
     """``y = x @ weight^T + bias (+ residual)`` with ``weight [out, in]``; any leading dims on ``x``.
     ``weight_lp_t`` is the optional bf16 ``[in, out]`` twin the input gradient multiplies by; ``residual`` (the
-    output's shape) is added in the GEMM epilogue."""
+    output's shape) is added in the GEMM epilogue; ``pre_gelu``: ``y = gelu_tanh(x) @ weight^T ...`` with the GELU's
+    backward folded into the input-gradient GEMM's epilogue."""
     if _ext.use_hip(x):
         lead = x.shape[:-1]
         cin, cout = weight.shape[1], weight.shape[0]
         x4 = x.reshape(-1, 1, 1, cin)
         wt = None if weight_lp_t is None else weight_lp_t.view(cin, 1, 1, cout)
         r4 = None if residual is None else residual.contiguous().reshape(-1, 1, 1, cout)
-        y, _ = _ConvFn.apply(x4, weight, weight_lp, bias, 1, 0, False, 0, (cout, 1, 1, cin), None, wt, r4)
+        y, _ = _ConvFn.apply(x4.contiguous(), weight, weight_lp, bias, 1, 0, False, 0, (cout, 1, 1, cin), None, wt, r4, pre_gelu)
         return y.reshape(*lead, cout)
+    if pre_gelu:
+        x = F.gelu(x, approximate="tanh")
     y = F.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
     return y if residual is None else y + residual

@@ -438,3 +438,15 @@ def test_dgrad_with_fused_bn_backward_statistics(case):
     _close(co[0], dg_ref, 1e-2, 5e-3 * sc, "dgamma")
     _close(co[1], db_ref, 1e-2, 5e-3 * sc, "dbeta")
     _close(dx, dx_ref.float(), 2e-2, 2e-2, "dx", max_bad_frac=1e-3)
+
+
+def test_dgrad_with_gelu_backward_epilogue():
+    """conv_dgrad(..., gelu_x=h) == conv_dgrad(...) * gelu'(h) (the ew2 mode-4 kernel)."""
+    C_ = _C()
+    M, K, Cc = 512, 256, 768
+    dy = _rand_bf16(M, 1, 1, K, scale=0.2, seed=61)
+    wt = C_.transpose_filter(_rand_bf16(K, 1, 1, Cc, scale=0.1, seed=62))
+    h = _rand_bf16(M, 1, 1, Cc, scale=1.5, seed=63)
+    ref = C_.ew2(C_.conv_dgrad(dy, wt, 1, 1, 1, 0, None, None), h, 4)
+    got = C_.conv_dgrad(dy, wt, 1, 1, 1, 0, None, None, None, None, None, h)
+    _close(got, ref.float(), 2e-2, 2e-3, "gelu-backward epilogue", max_bad_frac=1e-3)
