@@ -105,12 +105,22 @@ def _wgrad(C, conv, x, dy, grads, slot, in_line=False):
         grads[slot] = dw
 
 
+class _Link:
+    """What ONE forward call of a bottleneck leaves for the backward of the block that consumes its output (and what
+    that backward leaves for this block's): per call, not per module - under a pipeline schedule several micro-batches
+    are in flight through the same module."""
+    __slots__ = ("blk", "c3", "k3", "stats_for")
+
+    def __init__(self, blk):
+        self.blk, self.c3, self.k3, self.stats_for = blk, None, None, None
+
+
 class _BottleneckFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, blk, prev, *params):
+    def forward(ctx, x, blk, prev, link, *params):
         C = _ext.load()
         ds = blk.downsample is not None
-        ctx.prev = prev                 # the bottleneck whose output x is (or None): see _CROSS_BN3 below
+        ctx.prev, ctx.link = prev, link  # links of the block whose output x is (or None) and of this call (_CROSS_BN3)
         ds_done = None
         if ds and _DS_SIDE and _side.active(x):
             # the projection shortcut is independent of conv1 -> conv2: it runs on the side stream beside them
@@ -147,8 +157,8 @@ class _BottleneckFn(torch.autograd.Function):
         ctx.save_for_backward(*saved)
         ctx.blk = blk
         # what the NEXT block's backward needs to fold this block's bn3 reduction pass into its last dgrad
-        blk._bn3_saved = None if recompute else (c3, k3)
-        blk._bn3_stats_for = None
+        if not recompute:
+            link.c3, link.k3 = c3, k3
         return out
 
     @staticmethod
@@ -190,10 +200,10 @@ class _BottleneckFn(torch.autograd.Function):
             else:
                 grads[7], grads[8] = co[0], co[1]
             d3 = C.conv_bnb_apply(a2, w3, 1, 0, dout, k3, co[2], co[3], co[4])
-        elif getattr(blk, "_bn3_stats_for", None) is not None:
+        elif ctx.link.stats_for is not None:
             # the block after this one already accumulated bn3's reduction pass while writing dout (_CROSS_BN3)
             sb = blk.bn3.stats_buffer_bwd(dout.device)
-            if blk._bn3_stats_for == (dout.data_ptr(), tuple(dout.shape)):
+            if ctx.link.stats_for == (dout.data_ptr(), tuple(dout.shape)):
                 tg, tb = _sink.target(blk.bn3.weight), _sink.target(blk.bn3.bias)
                 sunk = tg is not None and tb is not None
                 co = C.bn_bwd_coefs(sb, dout.numel() // dout.shape[-1], blk.bn3.weight.detach(), m3, i3,
@@ -206,10 +216,10 @@ class _BottleneckFn(torch.autograd.Function):
             else:                       # dout is not the tensor those statistics were taken from (another consumer
                 sb.zero_()              # of the block output added its gradient): discard them
                 d3 = _bn_bwd(C, blk.bn3, dout, k3, c3, m3, i3, True, grads, 7)
-            blk._bn3_stats_for = None
+            ctx.link.stats_for = None
         else:
             d3 = _bn_bwd(C, blk.bn3, dout, k3, c3, m3, i3, True, grads, 7)
-        blk._bn3_saved = None
+        ctx.link.c3 = ctx.link.k3 = None
         # each wgrad goes to the side stream BEFORE the dgrad that shares its operand is enqueued: the two GEMMs
         # run side by side and the wgrad's tail overlaps the next BatchNorm backward (measured better than
         # enqueueing it after the dgrad, and better than keeping the HBM-bound stage-1/2 1x1 wgrads in line)
@@ -223,9 +233,8 @@ class _BottleneckFn(torch.autograd.Function):
         # bn3 of the PREVIOUS block: its incoming gradient is the dx this block is about to write, so the reduction
         # pass of its backward (sum g', sum g' * c3 under its ReLU bits) rides this dgrad's epilogue
         prev, bn_args = ctx.prev, (None, None, None)
-        if (_CROSS_BN3 and need_dx and prev is not None and getattr(prev, "_bn3_saved", None) is not None
-                and prev._bn3_saved[0].shape == x.shape):
-            bn_args = (prev._bn3_saved[0], prev._bn3_saved[1], prev.bn3.stats_buffer_bwd(dout.device))
+        if _CROSS_BN3 and need_dx and prev is not None and prev.c3 is not None and prev.c3.shape == x.shape:
+            bn_args = (prev.c3, prev.k3, prev.blk.bn3.stats_buffer_bwd(dout.device))
         if ds_done is not None:
             _side.wait(ds_done, ds_box)
             dx = C.conv_dgrad(d1, _wt(C, blk.conv1), x.shape[1], x.shape[2], 1, 0, ds_box[0], None, *bn_args)
@@ -241,8 +250,8 @@ class _BottleneckFn(torch.autograd.Function):
             # identity shortcut: the masked residual gradient is added in the dgrad epilogue
             dx = C.conv_dgrad(d1, _wt(C, blk.conv1), x.shape[1], x.shape[2], 1, 0, dout, k3, *bn_args)
         if bn_args[0] is not None and dx is not None:
-            prev._bn3_stats_for = (dx.data_ptr(), tuple(dx.shape))
-        return (dx, None, None, *grads)
+            prev.stats_for = (dx.data_ptr(), tuple(dx.shape))
+        return (dx, None, None, None, *grads)
 
 
 def bottleneck_params(blk):
@@ -262,8 +271,9 @@ def can_fuse(blk, x: torch.Tensor) -> bool:
 def bottleneck(blk, x: torch.Tensor) -> torch.Tensor:
     """Fused bottleneck block (GPU, training, bf16 shadows present).  Consecutive blocks are linked through a tensor
     attribute so that a block's backward can serve the bn3 of the block before it (see _BottleneckFn.backward)."""
-    out = _BottleneckFn.apply(x, blk, getattr(x, "_dpa_producer", None), *bottleneck_params(blk))
-    out._dpa_producer = blk
+    link = _Link(blk)
+    out = _BottleneckFn.apply(x, blk, getattr(x, "_dpa_producer", None), link, *bottleneck_params(blk))
+    out._dpa_producer = link
     return out
 
 

@@ -53,6 +53,7 @@ class DataParallel:
         self._sync = True
         self._armed = False
         self._launched: List[Bucket] = []
+        self._next_bucket = 0
         self.stats = {"allreduce_calls": 0, "allreduce_bytes": 0}
         for p in self.flat.params:
             p.register_post_accumulate_grad_hook(self._on_grad)
@@ -79,6 +80,7 @@ class DataParallel:
             b.pending = sum(1 for _ in b.param_indices)
             b.work = None
         self._launched = []
+        self._next_bucket = 0
         self._armed = True
 
     def no_sync(self):
@@ -109,7 +111,17 @@ class DataParallel:
         b = self._bucket_of[pid]
         b.pending -= 1
         if b.pending == 0:
-            self._launch(b)
+            self._launch_in_order()
+
+    def _launch_in_order(self) -> None:
+        """Launch every complete bucket whose predecessors have all been launched.  Collectives are matched across
+        ranks by call order, so the order must not depend on the order in which gradients happen to become ready
+        on a rank: buckets always go out in index order (= backward order, so nothing is held back in practice)."""
+        while self._next_bucket < len(self.buckets) and self.buckets[self._next_bucket].pending == 0:
+            b = self.buckets[self._next_bucket]
+            self._next_bucket += 1
+            if b.work is None:
+                self._launch(b)
 
     def _on_grad(self, p: torch.Tensor) -> None:          # autograd wrote p.grad (in place into the flat view)
         self._mark(p)
