@@ -54,7 +54,8 @@ def dp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, buc
         backend = "gloo"
     else:
         device = torch.device("cpu")
-    comm = dcomm.init_process_group(backend, url, global_rank, world_size, 60.0, device)
+    # two processes time-share one GPU under gloo_gpu: a cold box can stall a rank for tens of seconds
+    comm = dcomm.init_process_group(backend, url, global_rank, world_size, 180.0 if device.type == "cuda" else 60.0, device)
     model, loss_fn, shape, classes = _make_model(model_name)
     model = model.to(device)
     n_global = 8 * world_size
