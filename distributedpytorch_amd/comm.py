@@ -25,6 +25,8 @@ import torch
 import torch.distributed as dist
 
 _SYNC_DEBUG = os.environ.get("DPA_SYNC_DEBUG", "0") == "1"
+# DPA_FORCE_COLLECTIVES=1: issue the real collective even at world size 1 (tests: the whole RCCL call path on one GPU)
+_FORCE_COLLECTIVES = os.environ.get("DPA_FORCE_COLLECTIVES", "0") == "1"
 
 
 def set_sync_debug(flag: bool) -> None:
@@ -52,6 +54,11 @@ def rccl_env_defaults() -> None:
     overlapped backward kernels.
     """
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (required by the host driver)
+    # compute + weight-gradient side stream + RCCL's stream must not share hardware queues (HIP maps a process's
+    # streams onto GPU_MAX_HW_QUEUES queues, default 4: -9 % on ResNet-50 when two of them alias).  Only effective
+    # when this runs before the first HIP call of the process; bench.py / launch.py also set it at start-up.
+    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
     os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
 
 
@@ -204,7 +211,7 @@ class Communicator:
                     return work
                 work.wait()
                 return None
-        if self.world_size == 1:
+        if self.world_size == 1 and not (_FORCE_COLLECTIVES and dist.is_initialized()):
             return _DoneWork() if async_op else None
         work = dist.all_reduce(tensor, op=op, group=self.group, async_op=True)
         if _SYNC_DEBUG:

@@ -81,6 +81,8 @@ class ChildFailed(RuntimeError):
 def _child_entry(fn, local_rank, global_rank, world_size, args, err_queue):
     # Keep IPC in dmabuf mode for RCCL / tensor sharing on this driver stack.
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:       # compute / side / RCCL streams on separate hardware queues
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"                   # (comm.rccl_env_defaults); before the child's first HIP call
     os.environ["LOCAL_RANK"] = str(local_rank)
     os.environ["RANK"] = str(global_rank)
     os.environ["WORLD_SIZE"] = str(world_size)

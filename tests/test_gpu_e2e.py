@@ -274,3 +274,47 @@ def test_two_ranks_share_the_gpu_and_match_the_cpu_reference(tmp_path, model_nam
     assert finals[0]["calls"] >= 3
     for name in finals[0]["params"]:
         assert torch.equal(finals[0]["params"][name], finals[1]["params"][name]), f"replicas diverged at {name}"
+
+
+def _rccl_world1_worker(local_rank, global_rank, world_size, url, out_dir):
+    import os
+    import torch
+    from distributedpytorch_amd import comm as dcomm
+    from distributedpytorch_amd.models import resnet
+    from distributedpytorch_amd.optim import FusedSGD
+    from distributedpytorch_amd.parallel.dp import DataParallel
+    dcomm._FORCE_COLLECTIVES = True                    # what DPA_FORCE_COLLECTIVES=1 sets at import
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    comm = dcomm.init_process_group("nccl", url, 0, 1, 120.0, dev)
+    torch.manual_seed(11)
+    m = resnet.tiny_resnet().to(dev).train()
+    x = torch.randn(16, 3, 64, 64, device=dev); y = torch.randint(0, 16, (16,), device=dev)
+    dp = DataParallel(m, comm, bucket_mb=0.05, first_bucket_mb=0.01)
+    opt = FusedSGD(dp.flat, lr=0.05, momentum=0.9)
+    losses = []
+    for _ in range(6):
+        loss = m.loss(x, y); loss.backward(); dp.finish(); opt.step()
+        losses.append(float(loss.detach()))
+    comm.barrier()
+    torch.save({"losses": losses, "calls": dp.stats["allreduce_calls"], "buckets": len(dp.buckets)}, os.path.join(out_dir, "r.pt"))
+    dcomm.destroy_process_group()
+
+
+def test_dp_engine_over_real_rccl_collectives_at_world_size_one(tmp_path):
+    """The N-GPU call path on one GPU: c10d's RCCL process group (one rank), every bucket all-reduced for real on
+    RCCL's stream during backward, side-stream joins in front of each launch, optimizer behind the waits.  The
+    losses must equal a run without any communicator."""
+    from distributedpytorch_amd import launch
+    from distributedpytorch_amd.utils import testing as T
+    url = f"tcp://127.0.0.1:{T.free_port()}"
+    launch.spawn(_rccl_world1_worker, [1], 0, args=(url, str(tmp_path)))
+    r = torch.load(tmp_path / "r.pt", weights_only=True)
+    assert r["buckets"] >= 2 and r["calls"] >= 6 * r["buckets"]
+    torch.manual_seed(11)
+    from distributedpytorch_amd.models import resnet
+    m = resnet.tiny_resnet().to(DEV).train()
+    x = torch.randn(16, 3, 64, 64, device=DEV); y = torch.randint(0, 16, (16,), device=DEV)
+    losses, _, _ = _train(m, x, y, 6, lr=0.05)
+    for a, b in zip(r["losses"], losses):
+        assert abs(a - b) < 0.05 * max(1.0, abs(b)), (r["losses"], losses)
