@@ -366,8 +366,10 @@ std::vector<Tensor> bn_finalize(const Tensor& stats_in, int64_t P, const Tensor&
 }
 
 // returns (y, mask): mask is the uint8 bit mask (y > 0) when relu && want_mask, else undefined
+// res_scale / res_shift: the residual is a RAW conv output with its own BatchNorm (projection shortcut) - its affine is
+// applied on the fly, so that BatchNorm needs no apply pass of its own.
 std::vector<Tensor> bn_apply(const Tensor& x, const c10::optional<Tensor>& residual, const Tensor& scale, const Tensor& shift,
-                             bool relu, bool want_mask) {
+                             bool relu, bool want_mask, const c10::optional<Tensor>& res_scale, const c10::optional<Tensor>& res_shift) {
     CHECK_BF16(x); CHECK_F32(scale); CHECK_F32(shift);
     const int64_t C = x.size(-1), P = x.numel() / C;
     TORCH_CHECK(C % 8 == 0 && scale.numel() == C && shift.numel() == C, "bn_apply: bad channel count");
@@ -381,8 +383,15 @@ std::vector<Tensor> bn_apply(const Tensor& x, const c10::optional<Tensor>& resid
     Tensor y = torch::empty_like(x);
     Tensor mask;
     if (relu && want_mask) mask = torch::empty({x.numel() / 8}, x.options().dtype(at::kByte));
+    const float* rs = nullptr; const float* rb = nullptr;
+    if (res_scale.has_value() && res_scale->defined()) {
+        TORCH_CHECK(res != nullptr && res_shift.has_value() && res_shift->defined(), "bn_apply: res_scale needs residual and res_shift");
+        CHECK_F32((*res_scale)); CHECK_F32((*res_shift));
+        TORCH_CHECK(res_scale->numel() == C && res_shift->numel() == C, "bn_apply: res_scale / res_shift size");
+        rs = res_scale->data_ptr<float>(); rb = res_shift->data_ptr<float>();
+    }
     dpa::bn_apply(x.data_ptr(), res, y.data_ptr(), scale.data_ptr<float>(), shift.data_ptr<float>(),
-                  mask.defined() ? mask.data_ptr<uint8_t>() : nullptr, P, C, relu, cur_stream());
+                  mask.defined() ? mask.data_ptr<uint8_t>() : nullptr, P, C, relu, rs, rb, cur_stream());
     return {y, mask};
 }
 
@@ -790,7 +799,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("colsum", &colsum);
     m.def("bn_stats", &bn_stats);
     m.def("bn_finalize", &bn_finalize);
-    m.def("bn_apply", &bn_apply);
+    m.def("bn_apply", &bn_apply, py::arg("x"), py::arg("residual"), py::arg("scale"), py::arg("shift"), py::arg("relu"),
+          py::arg("want_mask"), py::arg("res_scale") = py::none(), py::arg("res_shift") = py::none());
     m.def("relu_mask_mul", &relu_mask_mul);
     m.def("bn_backward", &bn_backward);
     m.def("bn_relu_maxpool_fwd", &bn_relu_maxpool_fwd);

@@ -82,7 +82,9 @@ void bn_finalize(float* stats, int rows, long P, int C, const float* gamma, cons
 // y = act(x*scale[c] + shift[c] (+ residual))
 // relu: optionally also emits the bit mask (y > 0), one byte per 8 elements, that the backward kernels read
 void bn_apply(const void* x, const void* residual, void* y, const float* scale, const float* shift,
-              unsigned char* mask, long P, int C, int relu, hipStream_t st);
+              unsigned char* mask, long P, int C, int relu,
+              const float* rscale, const float* rshift /* optional per-channel affine of the residual, or nullptr */,
+              hipStream_t st);
 // backward pass 1: g = dy * (relu ? mask : 1); partial sums of g and g*xhat per block of rows
 // (replicas > 0: added with atomics into a zeroed [replicas][2][C] buffer instead)
 void bn_bwd_stats(const void* dy, const unsigned char* mask, const void* x, const float* mean, const float* invstd,

@@ -115,7 +115,8 @@ template <bool RELU, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ res,
                                                        unsigned short* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, unsigned char* __restrict__ mask,
-                                                       long nchunks, int cpr) {
+                                                       long nchunks, int cpr, const float* __restrict__ rscale,
+                                                       const float* __restrict__ rshift) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long)gridDim.x * 256) {
         const int ch = (int)(i % cpr);
         uint4 v = *(const uint4*)(x + i * 8);
@@ -125,7 +126,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
         const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
         const float sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         float r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (RES) { uint4 rv = *(const uint4*)(res + i * 8); unpack8(rv, r); }
+        if (RES) {
+            uint4 rv = *(const uint4*)(res + i * 8); unpack8(rv, r);
+            if (rscale != nullptr) {   // the residual is itself a raw conv output behind its own BatchNorm (projection shortcut)
+                const float4 q0 = *(const float4*)(rscale + ch * 8), q1 = *(const float4*)(rscale + ch * 8 + 4);
+                const float4 p0 = *(const float4*)(rshift + ch * 8), p1 = *(const float4*)(rshift + ch * 8 + 4);
+                const float rs[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                const float rb[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = r[j] * rs[j] + rb[j];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float t = f[j] * sc[j] + sh[j] + r[j];
@@ -382,17 +393,17 @@ void bn_finalize(float* stats, int rows, long P, int C, const float* gamma, cons
 }
 
 void bn_apply(const void* x, const void* residual, void* y, const float* scale, const float* shift,
-              unsigned char* mask, long P, int C, int relu, hipStream_t st) {
+              unsigned char* mask, long P, int C, int relu, const float* rscale, const float* rshift, hipStream_t st) {
     const long nchunks = P * C / 8;
     const int cpr = C / 8;
     dim3 g(stream_grid(nchunks)), b(256);
     auto X = (const unsigned short*)x; auto R = (const unsigned short*)residual; auto Y = (unsigned short*)y;
     if (relu) {
-        if (R) hipLaunchKernelGGL((bn_apply_kernel<true, true>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr);
-        else   hipLaunchKernelGGL((bn_apply_kernel<true, false>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr);
+        if (R) hipLaunchKernelGGL((bn_apply_kernel<true, true>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift);
+        else   hipLaunchKernelGGL((bn_apply_kernel<true, false>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift);
     } else {
-        if (R) hipLaunchKernelGGL((bn_apply_kernel<false, true>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr);
-        else   hipLaunchKernelGGL((bn_apply_kernel<false, false>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr);
+        if (R) hipLaunchKernelGGL((bn_apply_kernel<false, true>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift);
+        else   hipLaunchKernelGGL((bn_apply_kernel<false, false>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift);
     }
 }
 

@@ -33,15 +33,30 @@ ENABLED = os.environ.get("DPA_NO_FUSED_BLOCK", "0") != "1"
 # is as good a streamer as norm.hip.
 RECOMPUTE_MIN_BYTES = int(float(os.environ.get("DPA_RECOMPUTE_MB", "1e12")) * 2 ** 20)
 _DS_SIDE = os.environ.get("DPA_DS_SIDE", "1") != "0"
+_FOLD_DS_APPLY = os.environ.get("DPA_NO_FOLD_DS_APPLY", "0") != "1"
 
 
-def _conv_bn_fwd(C, conv, bn, x, relu, residual=None):
+def _conv_bn_fwd(C, conv, bn, x, relu, residual=None, res_affine=None):
     y, stats = C.conv_fprop(x, conv.weight_lp, None, conv.stride, conv.padding, 0, True, bn.stats_buffer(x.device))
     P = y.numel() // y.shape[-1]
     mean, invstd, scale, shift = C.bn_finalize(stats, P, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                                bn.running_var, bn.momentum, bn.eps, True)
-    a, mask = C.bn_apply(y, residual, scale, shift, relu, relu)
+    if res_affine is not None:
+        a, mask = C.bn_apply(y, residual, scale, shift, relu, relu, res_affine[0], res_affine[1])
+    else:
+        a, mask = C.bn_apply(y, residual, scale, shift, relu, relu)
     return y, a, mean, invstd, mask
+
+
+def _conv_bn_stats_only(C, conv, bn, x):
+    """Conv + the BatchNorm's statistics, WITHOUT its apply pass: for the projection shortcut, whose normalised
+    output is only ever added to bn3's - bn3's apply kernel applies (scale, shift) to the raw conv output as it
+    reads it, so the shortcut's own read-write pass over the block's widest tensor is gone."""
+    y, stats = C.conv_fprop(x, conv.weight_lp, None, conv.stride, conv.padding, 0, True, bn.stats_buffer(x.device))
+    P = y.numel() // y.shape[-1]
+    mean, invstd, scale, shift = C.bn_finalize(stats, P, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                                               bn.running_var, bn.momentum, bn.eps, True)
+    return y, mean, invstd, scale, shift
 
 
 def _bn_bwd(C, bn, dy, mask, x_raw, mean, invstd, relu, grads, slot):
@@ -122,23 +137,37 @@ class _BottleneckFn(torch.autograd.Function):
         ds = blk.downsample is not None
         ctx.prev, ctx.link = prev, link  # links of the block whose output x is (or None) and of this call (_CROSS_BN3)
         ds_done = None
+        conv3, bn3 = blk.conv3, blk.bn3
+        s2 = blk.conv2.stride
+        out_bytes = x.shape[0] * -(-x.shape[1] // s2) * -(-x.shape[2] // s2) * conv3.weight_lp.shape[0] * 2
+        recompute = out_bytes >= RECOMPUTE_MIN_BYTES and conv3.stride == 1 and conv3.padding == 0
+        fold_ds = ds and _FOLD_DS_APPLY and not recompute
+        res_affine = None
+
+        def shortcut():
+            if fold_ds:
+                return _conv_bn_stats_only(C, blk.downsample[0], blk.downsample[1], x)
+            cd, idn, md, isd, _ = _conv_bn_fwd(C, blk.downsample[0], blk.downsample[1], x, False)
+            return cd, md, isd, idn, None
+
         if ds and _DS_SIDE and _side.active(x):
             # the projection shortcut is independent of conv1 -> conv2: it runs on the side stream beside them
             box = []
-            ds_done = _side.run(lambda: box.append(_conv_bn_fwd(C, blk.downsample[0], blk.downsample[1], x, False)), (x,))
-            cd, idn, md, isd, _ = box[0]
+            ds_done = _side.run(lambda: box.append(shortcut()), (x,))
+            cd, md, isd, r0, r1 = box[0]
         elif ds:
-            cd, idn, md, isd, _ = _conv_bn_fwd(C, blk.downsample[0], blk.downsample[1], x, False)
+            cd, md, isd, r0, r1 = shortcut()
         else:
             cd = md = isd = None
-            idn = x
+            r0, r1 = x, None
         c1, a1, m1, i1, k1 = _conv_bn_fwd(C, blk.conv1, blk.bn1, x, True)
         c2, a2, m2, i2, k2 = _conv_bn_fwd(C, blk.conv2, blk.bn2, a1, True)
         if ds_done is not None:
-            _side.wait(ds_done, (cd, idn, md, isd))
-        conv3, bn3 = blk.conv3, blk.bn3
-        out_bytes = a2.numel() // a2.shape[-1] * conv3.weight_lp.shape[0] * 2
-        recompute = out_bytes >= RECOMPUTE_MIN_BYTES and conv3.stride == 1 and conv3.padding == 0
+            _side.wait(ds_done, (cd, md, isd, r0) + ((r1,) if r1 is not None else ()))
+        if fold_ds:
+            idn, res_affine = cd, (r0, r1)
+        else:
+            idn = r0
         if recompute:
             sb = bn3.stats_buffer(x.device)
             C.conv_fprop_stats(a2, conv3.weight_lp, 1, 0, sb)
@@ -148,7 +177,7 @@ class _BottleneckFn(torch.autograd.Function):
             out, k3 = C.conv_bn_res_relu(a2, conv3.weight_lp, 1, 0, scale, shift, idn)
             c3 = a2.new_empty(0)                       # placeholder: the raw conv output does not exist
         else:
-            c3, out, m3, i3, k3 = _conv_bn_fwd(C, conv3, bn3, a2, True, idn)
+            c3, out, m3, i3, k3 = _conv_bn_fwd(C, conv3, bn3, a2, True, idn, res_affine)
         ctx.recompute = recompute
         # the ReLU masks travel as 1 bit per element: the backward pass never re-reads an activation for its sign
         saved = [x, c1, a1, m1, i1, k1, c2, a2, m2, i2, k2, c3, m3, i3, k3]

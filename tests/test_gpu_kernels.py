@@ -379,6 +379,24 @@ def test_causal_attention_fwd_bwd(B, T, H):
         _close(g[:, :, i], gr[:, :, i], 3e-2, 3e-2, "attention " + name)
 
 
+def test_bn_apply_with_affine_residual_matches_fp32_reference():
+    """bn_apply(x, r, ..., res_scale, res_shift): relu(x*s + b + (r*rs + rb)) - the projection shortcut's BatchNorm folded
+    into bn3's apply (ops/block.py fold_ds) - against the plain fp32 expression."""
+    C_ = _C()
+    N, H, W, C = 3, 7, 9, 72
+    x = _rand_bf16(N, H, W, C, seed=41); r = _rand_bf16(N, H, W, C, seed=42)
+    s, b, rs, rb = (torch.randn(C, device=DEV) for _ in range(4))
+    y, mask = C_.bn_apply(x, r, s, b, True, True, rs, rb)
+    ref = torch.relu(x.float() * s + b + (r.float() * rs + rb))
+    _close(y.float(), ref, 1e-2, 1e-2, "bn_apply affine residual")
+    # the two-pass form it replaces rounds the shortcut to bf16 in between: agree within that rounding
+    idn, _ = C_.bn_apply(r, None, rs, rb, False, False)
+    y2, mask2 = C_.bn_apply(x, idn, s, b, True, True)
+    _close(y.float(), y2.float(), 2e-2, 3e-2, "bn_apply vs two-pass")
+    with pytest.raises(RuntimeError):
+        C_.bn_apply(x, None, s, b, True, True, rs, rb)
+
+
 @pytest.mark.parametrize("shape", [(4, 32, 32, 64), (3, 17, 23, 16)])
 def test_fused_bn_relu_maxpool_matches_unfused_ops(shape):
     """bn_relu_maxpool_fwd / pool_bn_backward (the stem node) against bn_apply + maxpool and their backwards."""
