@@ -56,11 +56,30 @@ __device__ __forceinline__ void reduce_rows(F f, float* __restrict__ stats, long
 
 // column sums of a [rows][2][C] statistics buffer for channel c over rows rl, rl+4, ...; optionally re-zeroes
 // what it read (each (row, channel) is read by exactly one thread)
+// The finalize kernels are a handful of blocks on the critical path between two full-chip kernels, and in backward they
+// run beside a weight-gradient GEMM on the side stream that keeps the memory pipes busy: a load -> add -> store-zero
+// loop is one serialized round trip per row there (the stores may alias the next loads).  All of a pass's 16 loads are
+// issued before anything depends on them, the zeroing stores come last.
 __device__ __forceinline__ void sum_and_reset(float* stats, int rows, int C, int c, int rl, int reset, double& s, double& q) {
-    for (int r = rl; r < rows; r += 4) {
-        float* ps = stats + ((long)r * 2) * C + c;
-        s += ps[0]; q += ps[C];
-        if (reset) { ps[0] = 0.f; ps[C] = 0.f; }
+    for (int r0 = rl; r0 < rows; r0 += 32) {
+        float a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = r0 + 4 * j;
+            const float* ps = stats + ((long)r * 2) * C + c;
+            a[j] = r < rows ? ps[0] : 0.f;
+            b[j] = r < rows ? ps[C] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s += a[j]; q += b[j]; }
+        if (reset) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = r0 + 4 * j;
+                float* ps = stats + ((long)r * 2) * C + c;
+                if (r < rows) { ps[0] = 0.f; ps[C] = 0.f; }
+            }
+        }
     }
 }
 
@@ -184,6 +203,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     __shared__ double red[2][4][64];
     double s = 0.0, q = 0.0;
+    // per-channel operands of the closing arithmetic travel with the statistics loads, not after the barrier
+    float gam = 0.f, isf = 0.f, mf = 0.f, db0 = 0.f, dg0 = 0.f;
+    if (rl == 0 && c < C) {
+        gam = gamma[c]; isf = invstd[c]; mf = mean[c];
+        if (accumulate) { db0 = dbeta[c]; dg0 = dgamma[c]; }
+    }
     if (c < C) sum_and_reset(stats, rows, C, c, rl, reset, s, q);
     red[0][rl][threadIdx.x & 63] = s; red[1][rl][threadIdx.x & 63] = q;
     __syncthreads();
@@ -191,10 +216,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
         const int l = threadIdx.x & 63;
         s = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];   // sum g       = dbeta
         q = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];   // sum g*xhat  = dgamma
-        if (raw_x) q = (double)invstd[c] * (q - (double)mean[c] * s);    // came in as sum g*x
-        if (accumulate) { dbeta[c] += (float)s; dgamma[c] += (float)q; }
-        else { dbeta[c] = (float)s; dgamma[c] = (float)q; }
-        const double g = gamma[c], is = invstd[c], m = mean[c], invP = 1.0 / (double)P;
+        if (raw_x) q = (double)isf * (q - (double)mf * s);               // came in as sum g*x
+        dbeta[c] = db0 + (float)s; dgamma[c] = dg0 + (float)q;
+        const double g = gam, is = isf, m = mf, invP = 1.0 / (double)P;
         // dx = g*is*(gy - s/P - xhat*q/P),  xhat = (x-m)*is
         cA[c] = (float)(g * is);
         cB[c] = (float)(-g * is * is * q * invP);
