@@ -34,7 +34,7 @@ std::vector<Tensor> layernorm_fwd(const Tensor& x, const Tensor& g, const Tensor
 // `addend` (bf16, x's shape): dx += addend - the gradient of the residual connection that forks off in front of the LayerNorm
 std::vector<Tensor> layernorm_bwd(const Tensor& dy, const Tensor& x, const Tensor& g, const Tensor& mean, const Tensor& rstd,
                                   const c10::optional<Tensor>& dgamma_acc, const c10::optional<Tensor>& dbeta_acc,
-                                  const c10::optional<Tensor>& addend) {
+                                  const c10::optional<Tensor>& addend, bool defer_reduce) {
     CHECK_BF16(dy); CHECK_BF16(x); CHECK_F32(g); CHECK_F32(mean); CHECK_F32(rstd);
     const int64_t C = x.size(-1), rows = x.numel() / C;
     TORCH_CHECK(dy.numel() == x.numel() && C % 8 == 0 && C <= 2048 && g.numel() == C && mean.numel() == rows && rstd.numel() == rows,
@@ -52,6 +52,7 @@ std::vector<Tensor> layernorm_bwd(const Tensor& dy, const Tensor& x, const Tenso
     }
     dpa::layernorm_bwd(dy.data_ptr(), x.data_ptr(), g.data_ptr<float>(), mean.data_ptr<float>(), rstd.data_ptr<float>(),
                        dx.data_ptr(), pp, pp + (long)pr * C, pr, rows, C, ad, cur_stream());
+    if (defer_reduce) return {dx, part};   // the caller folds the partial sums later (ln_fold_partials), off the critical path
     const bool acc = dgamma_acc.has_value() && dgamma_acc->defined() && dbeta_acc.has_value() && dbeta_acc->defined();
     if (acc) {
         CHECK_F32((*dgamma_acc)); CHECK_F32((*dbeta_acc));
@@ -63,6 +64,19 @@ std::vector<Tensor> layernorm_bwd(const Tensor& dy, const Tensor& x, const Tenso
     float* o = dgb.data_ptr<float>();
     dpa::reduce_partials2(pp, pr, C, o, o + C, 0, cur_stream());
     return {dx, dgb[0], dgb[1]};
+}
+
+// part [2, rows, C] (what layernorm_bwd(..., defer_reduce=true) returned): column sums ADDED into dgamma_acc / dbeta_acc.
+// Nobody needs a LayerNorm's parameter gradients before the bucket all-reduce, so ops/norm.py runs this on the side
+// stream instead of between two kernels of the backward chain.
+void ln_fold_partials(const Tensor& part, Tensor& dgamma_acc, Tensor& dbeta_acc) {
+    CHECK_F32(part); CHECK_F32(dgamma_acc); CHECK_F32(dbeta_acc);
+    TORCH_CHECK(part.dim() == 3 && part.size(0) == 2, "ln_fold_partials: part must be [2, rows, C]");
+    const int64_t pr = part.size(1), C = part.size(2);
+    TORCH_CHECK(dgamma_acc.numel() == C && dbeta_acc.numel() == C, "ln_fold_partials: accumulator shapes");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(part.device());
+    const float* pp = part.data_ptr<float>();
+    dpa::reduce_partials2(pp, (int)pr, (int)C, dgamma_acc.data_ptr<float>(), dbeta_acc.data_ptr<float>(), 1, cur_stream());
 }
 
 // tokens [B,T] int64, wte [V,C] bf16, wpe [Tmax,C] bf16 -> [B,T,C] bf16
@@ -119,7 +133,9 @@ Tensor attention_bwd(const Tensor& qkv, const Tensor& out, const Tensor& dout, c
 void bind_transformer(pybind11::module_& m) {
     m.def("layernorm_fwd", &layernorm_fwd);
     m.def("layernorm_bwd", &layernorm_bwd, pybind11::arg("dy"), pybind11::arg("x"), pybind11::arg("g"), pybind11::arg("mean"),
-          pybind11::arg("rstd"), pybind11::arg("dgamma_acc"), pybind11::arg("dbeta_acc"), pybind11::arg("addend") = pybind11::none());
+          pybind11::arg("rstd"), pybind11::arg("dgamma_acc"), pybind11::arg("dbeta_acc"), pybind11::arg("addend") = pybind11::none(),
+          pybind11::arg("defer_reduce") = false);
+    m.def("ln_fold_partials", &ln_fold_partials);
     m.def("embedding_fwd", &embedding_fwd);
     m.def("embedding_bwd", &embedding_bwd);
 #ifdef DPA_HAVE_ATTENTION

@@ -109,7 +109,7 @@ class GPT2(nn.Module):
     def forward(self, tokens: torch.Tensor) -> torch.Tensor:
         """Logits ``[B, T, vocab_padded]`` (tied LM head; columns >= vocab_size are padding)."""
         x = self.hidden(tokens)
-        return ops.linear(x, self.emb.wte, self.emb.wte_lp, None)
+        return ops.linear(x, self.emb.wte, self.emb.wte_lp, None, plain=True)
 
     def loss(self, tokens: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
         logits = self.forward(tokens)
@@ -131,7 +131,7 @@ class _LMHead(nn.Module):
 
     def forward(self, x):
         m = self._model[0]
-        return ops.linear(self.ln_f(x), m.emb.wte, m.emb.wte_lp, None)
+        return ops.linear(self.ln_f(x), m.emb.wte, m.emb.wte_lp, None, plain=True)
 
 
 def gpt2_small() -> GPT2:

@@ -8,12 +8,14 @@ apply) with the ReLU mask and residual gradient folded in.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
 import torch.nn.functional as F
 
 from . import _ext
+from . import side as _side
 from . import sink as _sink
 
 
@@ -96,6 +98,20 @@ def batch_norm_nhwc(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
     return y.contiguous()
 
 
+_LN_FOLD_SIDE = os.environ.get("DPA_LN_FOLD_SIDE", "1") != "0"
+
+
+def _ln_bwd_into(C, dy, x, gamma, mean, rstd, tg, tb, addend):
+    """LayerNorm backward whose parameter gradients go straight into the flat gradient buffer.  The kernel leaves
+    per-block partial column sums; folding them (a 25 us latency-bound kernel, 25 of them per GPT-2 step) is work
+    nobody waits for before the bucket all-reduce, so it runs on the side stream (ops/side.py)."""
+    if _LN_FOLD_SIDE and _side.active(x):
+        dx, part = C.layernorm_bwd(dy, x, gamma, mean, rstd, None, None, addend, True)
+        _side.run(lambda: C.ln_fold_partials(part, tg, tb), (part,))
+        return dx
+    return C.layernorm_bwd(dy, x, gamma, mean, rstd, tg, tb, addend)[0]
+
+
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
@@ -111,7 +127,7 @@ class _LayerNormFn(torch.autograd.Function):
         x, mean, rstd = ctx.saved_tensors
         tg, tb = _sink.target(ctx.gamma), _sink.target(ctx.beta)
         if tg is not None and tb is not None:       # the fold kernel adds straight into the flat gradient buffer
-            dx, _, _ = C.layernorm_bwd(dy.contiguous(), x, ctx.gamma.detach(), mean, rstd, tg, tb)
+            dx = _ln_bwd_into(C, dy.contiguous(), x, ctx.gamma.detach(), mean, rstd, tg, tb, None)
             _sink.ready(ctx.gamma); _sink.ready(ctx.beta)
             return dx, None, None, None
         dx, dg, db = C.layernorm_bwd(dy.contiguous(), x, ctx.gamma.detach(), mean, rstd, None, None)
@@ -142,7 +158,7 @@ class _LayerNormForkFn(torch.autograd.Function):
         if dy is None:                      # the normalised branch was not used
             return dres, None, None, None
         if tg is not None and tb is not None:
-            dx, _, _ = C.layernorm_bwd(dy.contiguous(), x, ctx.gamma.detach(), mean, rstd, tg, tb, ad)
+            dx = _ln_bwd_into(C, dy.contiguous(), x, ctx.gamma.detach(), mean, rstd, tg, tb, ad)
             _sink.ready(ctx.gamma); _sink.ready(ctx.beta)
             return dx, None, None, None
         dx, dg, db = C.layernorm_bwd(dy.contiguous(), x, ctx.gamma.detach(), mean, rstd, None, None, ad)

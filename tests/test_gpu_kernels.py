@@ -322,6 +322,55 @@ def test_mnist_ops_match_torch():
             _close(a.grad, b.grad, 1e-3, 1e-5, "grad " + name)
 
 
+def test_plain_linear_library_path_matches_fp32_reference_and_own_kernels():
+    """ops.linear(plain=True) (LM head: forward / input gradient through the library GEMM, weight gradient through
+    conv_wgrad.hip) against the fp32 expression and against the all-own-kernel path."""
+    from distributedpytorch_amd import ops
+    from distributedpytorch_amd.ops import conv as convmod
+    M, K, N = 384, 128, 1000 + 24
+    x0 = _rand_bf16(3, M // 3, K, seed=51)
+    w0 = (torch.randn(N, K, generator=torch.Generator().manual_seed(52)) * 0.05).to(DEV)
+    dy = _rand_bf16(3, M // 3, N, scale=0.1, seed=53)
+    got = []
+    keep = convmod.LIBRARY_PLAIN_GEMM
+    try:
+        for lib in (True, False):
+            convmod.LIBRARY_PLAIN_GEMM = lib
+            x = x0.clone().requires_grad_(); w = w0.clone().requires_grad_()
+            y = ops.linear(x, w, None, None, plain=True)
+            y.backward(dy)
+            got.append((y.detach().float(), x.grad.float(), w.grad.float()))
+    finally:
+        convmod.LIBRARY_PLAIN_GEMM = keep
+    wr = w0.to(torch.bfloat16).float()
+    yr = x0.float() @ wr.t()
+    dxr = dy.float() @ wr
+    dwr = dy.float().reshape(-1, N).t() @ x0.float().reshape(-1, K)
+    for y, dx, dw in got:
+        _close(y, yr, 2e-2, 2e-2, "plain linear y")
+        _close(dx, dxr, 2e-2, 2e-2, "plain linear dx")
+        _close(dw, dwr, 2e-2, 2e-2, "plain linear dw")
+
+
+def test_layernorm_backward_deferred_fold_equals_direct():
+    """layernorm_bwd(defer_reduce=True) + ln_fold_partials (what ops/norm.py runs on the side stream) adds the same
+    parameter gradients as the one-call form."""
+    C_ = _C()
+    rows, C = 300, 768
+    x = _rand_bf16(rows, C, seed=61); dy = _rand_bf16(rows, C, scale=0.3, seed=62)
+    g = torch.rand(C, device=DEV) + 0.5; b = torch.zeros(C, device=DEV)
+    _, mean, rstd = C_.layernorm_fwd(x, g, b, 1e-5)
+    dg1 = torch.full((C,), 0.25, device=DEV); db1 = torch.full((C,), -0.5, device=DEV)
+    dg2, db2 = dg1.clone(), db1.clone()
+    dx1 = C_.layernorm_bwd(dy, x, g, mean, rstd, dg1, db1)[0]
+    dx2, part = C_.layernorm_bwd(dy, x, g, mean, rstd, None, None, None, True)
+    C_.ln_fold_partials(part, dg2, db2)
+    assert torch.equal(dx1, dx2)
+    _close(dg2, dg1, 1e-5, 1e-4, "dgamma"); _close(db2, db1, 1e-5, 1e-4, "dbeta")
+    xh = (x.float() - mean[:, None]) * rstd[:, None]
+    _close(dg2 - 0.25, (dy.float() * xh).sum(0), 1e-2, 2e-2, "dgamma vs fp32")
+
+
 def test_layernorm_gelu_embedding():
     from distributedpytorch_amd import ops
     x = _rand_bf16(37, 768, seed=21).requires_grad_()
