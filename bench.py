@@ -166,16 +166,21 @@ def main():
             opt.step()
             return loss
 
+        from distributedpytorch_amd.utils.gcguard import GCGuard
         for _ in range(args.warmup):
             step()
-        communicator.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
-        communicator.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        # the collector runs at a fixed step period, the same step on every rank (as in train.py): a generation-2
+        # pause on one rank is a pause of the whole synchronous job
+        with GCGuard(period=500) as guard:
+            communicator.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                loss = step()
+                guard.step()
+            communicator.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
         elapsed = communicator.all_reduce_scalar(elapsed, "max")
         result = {"elapsed": elapsed, "items_per_rank_step": items, "loss": float(loss.detach().float().cpu()),
                   "config": dict(cfg, parallelism=f"dp{world}", per_gpu_batch=batch,

@@ -23,6 +23,7 @@ from .optim import FusedSGD
 from .parallel.dp import DataParallel
 from .parallel.flat import FlatParams
 from .parallel.pp import PipelineStage, build_stage_module, partition_balanced, param_costs
+from .utils.gcguard import GCGuard
 
 
 def pick_device(cfg: TrainConfig, local_rank: int) -> torch.device:
@@ -91,6 +92,8 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
         if cfg.steps_per_epoch:
             num_batches = min(num_batches, cfg.steps_per_epoch)
         last = None
+        guard = GCGuard(period=500)      # collector at a fixed step period, the same step on every rank (utils/gcguard.py)
+        guard.__enter__()
         for epoch in range(start_epoch, cfg.epochs):
             loader.set_epoch(epoch)
             epoch_loss = torch.zeros((), device=device)
@@ -106,6 +109,7 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                     dmetrics.check_reduced_gradients(dp.flat, comm)
                 opt.step()                               # fused: scale, momentum, update, bf16 shadow, zero grad
                 meter.update(x.shape[0])
+                guard.step()
             last = float(epoch_loss / num_batches)
             rate = meter.rate()
             print(dmetrics.epoch_line_dp(comm.rank, epoch, last), flush=True)            # DP.py:157
@@ -115,6 +119,7 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
             log.log(kind="dp_epoch", epoch=epoch, loss=last, samples_per_sec=total, world_size=world_size)
             if cfg.checkpoint:
                 save_checkpoint(cfg.checkpoint, model, opt, epoch, comm=comm)
+        guard.__exit__(None, None, None)
         return last
     finally:
         comm.barrier()

@@ -73,3 +73,21 @@ def test_spawn_kills_survivors_when_a_rank_dies():
         launch.spawn(T.crash_worker, [3], 0, args=(url,))
     assert time.time() - t0 < 60
     assert "injected failure" in str(e.value)
+
+
+def test_gc_guard_disables_collector_and_collects_on_a_fixed_period():
+    import gc
+    from distributedpytorch_amd.utils.gcguard import GCGuard
+    assert gc.isenabled()
+    seen = []
+    cb = lambda phase, info: seen.append(info["generation"]) if phase == "start" else None  # noqa: E731
+    with GCGuard(period=3) as guard:
+        assert not gc.isenabled()
+        gc.callbacks.append(cb)
+        try:
+            for _ in range(7):
+                guard.step()
+        finally:
+            gc.callbacks.remove(cb)
+    assert gc.isenabled()
+    assert seen == [1, 1]          # steps 3 and 6, nothing in between
