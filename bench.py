@@ -83,8 +83,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); none visible")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # DPA_SHARE_GPU=1: every rank on GPU 0 (rehearsal of the multi-rank flows on a one-GPU box, with --backend gloo:
+    # RCCL refuses two ranks on one device); the number it prints is not a benchmark result
+    if os.environ.get("DPA_HANG_DUMP"):     # dump every thread's Python stack and exit if the run is still going after N s
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["DPA_HANG_DUMP"]), exit=True)
+    dev_index = 0 if os.environ.get("DPA_SHARE_GPU", "0") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
 
     from distributedpytorch_amd import comm as dcomm
     from distributedpytorch_amd.optim import FusedSGD

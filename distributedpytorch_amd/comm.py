@@ -27,6 +27,7 @@ import torch.distributed as dist
 _SYNC_DEBUG = os.environ.get("DPA_SYNC_DEBUG", "0") == "1"
 # DPA_FORCE_COLLECTIVES=1: issue the real collective even at world size 1 (tests: the whole RCCL call path on one GPU)
 _FORCE_COLLECTIVES = os.environ.get("DPA_FORCE_COLLECTIVES", "0") == "1"
+_GLOO_NATIVE_DEVICE = os.environ.get("DPA_GLOO_DEVICE", "staged").lower() == "native"
 
 
 def set_sync_debug(flag: bool) -> None:
@@ -135,6 +136,24 @@ class _DoneWork:
         return True
 
 
+class _StagedWork:
+    """Handle of a device-tensor transfer staged through host memory (gloo): ``wait()`` completes the host transfer
+    and, for a receive, copies into the device tensor."""
+
+    def __init__(self, work, host: torch.Tensor, target: Optional[torch.Tensor]):
+        self.work, self.host, self.target = work, host, target
+
+    def wait(self):
+        self.work.wait()
+        if self.target is not None:
+            self.target.copy_(self.host)
+            self.target = None
+        return True
+
+    def is_completed(self) -> bool:
+        return self.work.is_completed()
+
+
 class Communicator:
     """Thin, group-scoped view of the process group.
 
@@ -213,6 +232,13 @@ class Communicator:
                 return None
         if self.world_size == 1 and not (_FORCE_COLLECTIVES and dist.is_initialized()):
             return _DoneWork() if async_op else None
+        if self._staged(tensor) and not _GLOO_NATIVE_DEVICE:
+            host = tensor.cpu()
+            work = _StagedWork(dist.all_reduce(host, op=op, group=self.group, async_op=True), host, tensor)
+            if async_op:
+                return work
+            work.wait()
+            return None
         work = dist.all_reduce(tensor, op=op, group=self.group, async_op=True)
         if _SYNC_DEBUG:
             work.wait()
@@ -246,6 +272,13 @@ class Communicator:
     def broadcast(self, tensor: torch.Tensor, src: int = 0, async_op: bool = False):
         if self.world_size == 1:
             return _DoneWork() if async_op else None
+        if self._staged(tensor) and not _GLOO_NATIVE_DEVICE:
+            host = tensor.cpu()
+            work = _StagedWork(dist.broadcast(host, src=self.to_global(src), group=self.group, async_op=True), host, tensor)
+            if async_op:
+                return work
+            work.wait()
+            return None
         work = dist.broadcast(tensor, src=self.to_global(src), group=self.group, async_op=True)
         if async_op and not _SYNC_DEBUG:
             return work
@@ -260,20 +293,42 @@ class Communicator:
                 dist.barrier(group=self.group)
 
     # ---- point to point (reference: MP.py:140,144,153,167) ----
+    def _staged(self, tensor: torch.Tensor) -> bool:
+        """A device tensor under ``--backend gloo`` (the reference's default, and what its MP README prescribes,
+        multinode-MP/README.md:11) goes through a host copy, as in MP.py:139-145: gloo's point-to-point moves host
+        memory only, and its own device-tensor collectives stopped making progress on a 102 MB broadcast on ROCm
+        (ResNet-50's flat parameter buffer, two ranks; small tensors worked).  ``DPA_GLOO_DEVICE=native`` hands
+        device tensors to gloo's collectives anyway.  Under RCCL nothing ever leaves the device."""
+        return tensor.is_cuda and self.backend != "nccl"
+
     def send(self, tensor: torch.Tensor, dst: int):
+        if self._staged(tensor):
+            dist.send(tensor.cpu(), dst=self.to_global(dst), group=self.group)
+            return
         dist.send(tensor, dst=self.to_global(dst), group=self.group)
         if _SYNC_DEBUG and tensor.is_cuda:
             torch.cuda.synchronize(tensor.device)
 
     def recv(self, tensor: torch.Tensor, src: int):
+        if self._staged(tensor):
+            host = torch.empty(tensor.shape, dtype=tensor.dtype)
+            dist.recv(host, src=self.to_global(src), group=self.group)
+            tensor.copy_(host)
+            return
         dist.recv(tensor, src=self.to_global(src), group=self.group)
         if _SYNC_DEBUG and tensor.is_cuda:
             torch.cuda.synchronize(tensor.device)
 
     def isend(self, tensor: torch.Tensor, dst: int):
+        if self._staged(tensor):
+            host = tensor.cpu()
+            return _StagedWork(dist.isend(host, dst=self.to_global(dst), group=self.group), host, None)
         return dist.isend(tensor, dst=self.to_global(dst), group=self.group)
 
     def irecv(self, tensor: torch.Tensor, src: int):
+        if self._staged(tensor):
+            host = torch.empty(tensor.shape, dtype=tensor.dtype)
+            return _StagedWork(dist.irecv(host, src=self.to_global(src), group=self.group), host, tensor)
         return dist.irecv(tensor, src=self.to_global(src), group=self.group)
 
     def batch_p2p(self, ops: List[tuple]):
@@ -281,6 +336,8 @@ class Communicator:
         call (ncclGroupStart/End) so a send and a recv to neighbours cannot deadlock."""
         if not ops:
             return []
+        if any(self._staged(t) for _, t, _ in ops):       # gloo: non-blocking host transfers, one handle per op
+            return [self.isend(t, peer) if kind == "send" else self.irecv(t, peer) for kind, t, peer in ops]
         p2p = []
         for kind, tensor, peer in ops:
             fn = dist.isend if kind == "send" else dist.irecv

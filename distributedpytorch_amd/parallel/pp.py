@@ -63,26 +63,35 @@ def param_costs(layers: Sequence[nn.Module]) -> List[float]:
     return [1.0 + sum(p.numel() for p in l.parameters()) for l in layers]
 
 
-def measure_costs(layers: Sequence[nn.Module], sample: torch.Tensor, iters: int = 2) -> List[float]:
+def measure_costs(layers: Sequence[nn.Module], sample: torch.Tensor, iters: int = 3) -> List[float]:
     """Forward+backward time of every layer on this device (stages must be balanced by
     TIME, not by layer count: early ResNet stages move far more activation bytes)."""
     costs = []
     x = sample
     use_cuda = sample.is_cuda
-    for layer in layers:
+
+    def once(layer, x, g):
         xin = x.detach().requires_grad_(x.is_floating_point())
         y = layer(xin)
+        y.backward(torch.ones_like(y) if g is None else g)
+        return y
+
+    for layer in layers:
+        # one untimed forward AND backward first: the first launch of a kernel loads its code object (milliseconds),
+        # and whichever layer meets a kernel first would be charged for it - a split measured that way put 49 of
+        # ResNet-152's 52 layers on the last of 4 stages
+        y = once(layer, x, None)
         g = torch.ones_like(y)
-        if use_cuda:
-            torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            xin2 = x.detach().requires_grad_(x.is_floating_point())
-            y2 = layer(xin2)
-            y2.backward(g)
-        if use_cuda:
-            torch.cuda.synchronize()
-        costs.append((time.perf_counter() - t0) / iters)
+        best = float("inf")
+        for _ in range(max(1, iters)):
+            if use_cuda:
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            once(layer, x, g)
+            if use_cuda:
+                torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)      # min, not mean: a neighbour's burst or a host hiccup only adds
+        costs.append(best)
         x = y.detach()
         for p in layer.parameters():
             p.grad = None

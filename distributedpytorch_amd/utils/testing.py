@@ -92,9 +92,16 @@ def dp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, buc
     dcomm.destroy_process_group()
 
 
-def pp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, stages, replicas, n_micro, schedule, batch, steps):
-    """Pipeline (x replicas) on gloo; writes per-stage grads after the first step and losses."""
-    world = dcomm.init_process_group("gloo", url, global_rank, world_size, 60.0, torch.device("cpu"))
+def pp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, stages, replicas, n_micro, schedule, batch, steps,
+              share_gpu=False):
+    """Pipeline (x replicas) on gloo; writes per-stage grads after the first step and losses.
+    ``share_gpu``: every stage runs the HIP engine on GPU 0 (fused blocks with several micro-batches in flight,
+    gradient sinks accumulating over micro-batches, side stream), activations travel host-staged over gloo."""
+    device = torch.device("cpu")
+    if share_gpu:
+        torch.cuda.set_device(0)
+        device = torch.device("cuda", 0)
+    world = dcomm.init_process_group("gloo", url, global_rank, world_size, 180.0 if share_gpu else 60.0, device)
     pp_comm, dp_comm, replica, stage = dcomm.build_grid(world, replicas, stages)
     if stage >= 0:
         torch.manual_seed(1234)
@@ -112,8 +119,9 @@ def pp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, sta
             stage_mod = build_stage_module(layers, bounds, stage, full)
             loss_fn, shape, classes = (lambda o, t: ops.softmax_cross_entropy(o, t, 16)), (3, 32, 32), 16
         x, y = _data(shape, classes, batch * replicas)
-        x, y = x[replica * batch:(replica + 1) * batch], y[replica * batch:(replica + 1) * batch]
-        dp = DataParallel(stage_mod, dp_comm) if replicas > 1 else None
+        x, y = x[replica * batch:(replica + 1) * batch].to(device), y[replica * batch:(replica + 1) * batch].to(device)
+        stage_mod = stage_mod.to(device)
+        dp = DataParallel(stage_mod, dp_comm) if (replicas > 1 or share_gpu) else None
         flat = dp.flat if dp is not None else FlatParams(stage_mod)
         opt = FusedSGD(flat, lr=0.05, momentum=0.0)
         if dp is not None:
@@ -124,7 +132,9 @@ def pp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, sta
             loss = eng.train_step(batch, x if eng.first else None, y if eng.last else None)
             if s == 0:
                 scale = opt.grad_scale if dp is not None else 1.0
-                torch.save({n: (p.grad * scale).clone() for n, p in stage_mod.named_parameters()},
+                if share_gpu:
+                    torch.cuda.synchronize()
+                torch.save({n: (p.grad * scale).detach().cpu().clone() for n, p in stage_mod.named_parameters()},
                            os.path.join(out_dir, f"grads_r{replica}_s{stage}.pt"))
             opt.step()
             if loss is not None:

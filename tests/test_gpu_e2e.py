@@ -376,3 +376,65 @@ def test_dp_engine_over_real_rccl_collectives_at_world_size_one(tmp_path):
     losses, _, _ = _train(m, x, y, 6, lr=0.05)
     for a, b in zip(r["losses"], losses):
         assert abs(a - b) < 0.05 * max(1.0, abs(b)), (r["losses"], losses)
+
+
+@pytest.mark.parametrize("model_name,stages,n_micro,batch", [("mnist", 2, 4, 16), ("tiny_resnet", 2, 4, 32)])
+def test_pipeline_stages_share_the_gpu_and_match_the_unsplit_cpu_model(tmp_path, model_name, stages, n_micro, batch):
+    """The pipeline engine with every stage on GPU 0 (one process per stage; activations and gradients host-staged
+    over gloo, the transport the reference's MP script uses): the HIP engine under a 1F1B schedule - several
+    micro-batches in flight through the same fused blocks, gradients accumulated over micro-batches in the flat
+    buffer - against the unsplit model on the CPU processing the same micro-batches."""
+    from distributedpytorch_amd import launch
+    from distributedpytorch_amd.parallel.pp import partition_balanced, param_costs
+    from distributedpytorch_amd.utils import testing as T
+    import test_pp_gloo as P
+    url = f"tcp://127.0.0.1:{T.free_port()}"
+    launch.spawn(T.pp_worker, [stages], 0, args=(url, model_name, str(tmp_path), stages, 1, n_micro, "1f1b", batch, 3, True))
+    layers, ref_loss = P._reference(model_name, batch, n_micro)
+    bounds = [(0, 1), (1, 2)] if model_name == "mnist" else partition_balanced(param_costs(layers), stages)
+    final = torch.load(tmp_path / f"final_r0_s{stages - 1}.pt", weights_only=True)
+    assert abs(final["losses"][0] - ref_loss) < (1e-4 if model_name == "mnist" else 0.05) * max(1.0, abs(ref_loss))
+    assert final["losses"][-1] < final["losses"][0]
+    num = den = 0.0
+    for s in range(stages):
+        a, b = bounds[s]
+        got = torch.load(tmp_path / f"grads_r0_s{s}.pt", weights_only=True)
+        for li in range(a, b):
+            for n, p in layers[li].named_parameters():
+                g = got[n if b - a == 1 else f"{li - a}.{n}"]
+                if model_name == "mnist":                      # fp32 kernels: per-tensor, tight
+                    assert torch.allclose(g, p.grad, rtol=2e-3, atol=2e-5), (s, n)
+                if g.shape == p.grad.shape:                    # (the stem filter is channel-padded on the GPU)
+                    num += float((g - p.grad).pow(2).sum()); den += float(p.grad.pow(2).sum())
+    if model_name != "mnist":
+        # bf16 activations, ReLU bits taken from rounded values: ONE process on the GPU is already 11-12 % (L2, all
+        # parameters) from the fp32 CPU gradient on this model; a dropped or doubled micro-batch would be >= 25 %
+        assert (num / den) ** 0.5 < 0.2, (num / den) ** 0.5
+        # the sharp check: the unsplit model on the GPU over the same micro-batches
+        from distributedpytorch_amd import ops
+        from distributedpytorch_amd.models import resnet
+        from distributedpytorch_amd.parallel.flat import FlatParams
+        from distributedpytorch_amd.parallel.pp import split_microbatches
+        torch.manual_seed(1234)
+        full = resnet.tiny_resnet().train().to(DEV)
+        FlatParams(full)
+        glayers = full.pipeline_layers()
+        x, y = T._data((3, 32, 32), 16, batch)
+        x, y = x.to(DEV), y.to(DEV)
+        off = 0
+        for sz in split_microbatches(batch, n_micro):
+            h = x[off:off + sz]
+            for l in glayers:
+                h = l(h)
+            (ops.softmax_cross_entropy(h, y[off:off + sz], 16) * (sz / float(batch))).backward()
+            off += sz
+        torch.cuda.synchronize()
+        num = den = 0.0
+        for s in range(stages):
+            a, b = bounds[s]
+            got = torch.load(tmp_path / f"grads_r0_s{s}.pt", weights_only=True)
+            for li in range(a, b):
+                for n, p in glayers[li].named_parameters():
+                    g = got[n if b - a == 1 else f"{li - a}.{n}"]
+                    num += float((g - p.grad.cpu()).pow(2).sum()); den += float(p.grad.pow(2).sum())
+        assert (num / den) ** 0.5 < 0.05, (num / den) ** 0.5
