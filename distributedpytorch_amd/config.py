@@ -93,7 +93,7 @@ class TrainConfig:
 def _common_flags(p: argparse.ArgumentParser) -> None:
     # Reference flags (kept verbatim so launch lines carry over).
     p.add_argument("--workers", default=0, type=int, metavar="N",
-                   help="data loading workers (synthetic data needs none)")
+                   help="host threads assembling batches ahead of the training loop (honoured, unlike the reference)")
     p.add_argument("--gpu", default=None, type=int, help="accepted for compatibility; device = local rank")
     p.add_argument("--rank", default=0, type=int, help="accepted for compatibility; rank comes from --GPU-list/--node-index")
     p.add_argument("--epochs", default=None, type=int, help="number of epochs (honoured, unlike the reference)")

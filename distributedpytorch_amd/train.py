@@ -31,8 +31,9 @@ def pick_device(cfg: TrainConfig, local_rank: int) -> torch.device:
     if want == "auto":
         want = "cuda" if (torch.cuda.is_available() and cfg.backend not in ("gloo",)) else "cpu"
     if want == "cuda":
-        torch.cuda.set_device(local_rank)
-        return torch.device("cuda", local_rank)
+        index = 0 if os.environ.get("DPA_SHARE_GPU", "0") == "1" else local_rank    # rehearsal: all ranks on GPU 0 (gloo)
+        torch.cuda.set_device(index)
+        return torch.device("cuda", index)
     return torch.device("cpu")
 
 
@@ -77,7 +78,8 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
         model, kind, loss_fn, use_lp, classes = build_model(cfg.model)
         model = model.to(device).train()
         dataset = build_dataset(kind, cfg, classes, model)
-        loader, bsz = ddata.partition_dataset(dataset, comm.rank, comm.world_size, cfg.batch_size, cfg.seed, device)
+        loader, bsz = ddata.partition_dataset(dataset, comm.rank, comm.world_size, cfg.batch_size, cfg.seed, device,
+                                              workers=max(1, cfg.workers))
         dp = DataParallel(model, comm, bucket_mb=cfg.bucket_mb, first_bucket_mb=cfg.first_bucket_mb,
                           use_lp=use_lp)                 # ... and a broadcast from rank 0 for safety
         opt = FusedSGD(dp.flat, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
@@ -165,7 +167,9 @@ def run_mp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
             part = ddata.DataPartitioner(dataset, [1.0 / replicas] * replicas, cfg.seed).use(replica)
         else:
             part = ddata.Partition(dataset, list(range(len(dataset))))
-        loader = ddata.BatchLoader(part, cfg.batch_size, shuffle=False, device=device)
+        loader = ddata.BatchLoader(part, cfg.batch_size, shuffle=False, device=None if device.type == "cuda" else device)
+        if device.type == "cuda":
+            loader = ddata.PrefetchLoader(loader, device, workers=max(1, cfg.workers))
         dp = DataParallel(stage_mod, dp_comm, use_lp=use_lp) if (dp_comm is not None) else None
         flat = dp.flat if dp is not None else FlatParams(stage_mod, use_lp=use_lp)
         opt = FusedSGD(flat, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)   # one optimizer per stage

@@ -1,6 +1,7 @@
 """T0: Partition / DataPartitioner semantics (reference DP.py:42-75)."""
 from random import Random
 
+import pytest
 import torch
 
 from distributedpytorch_amd import data
@@ -60,3 +61,44 @@ def test_synthetic_dataset_deterministic():
     t = data.SyntheticTokenDataset(10, 32, 100)
     x, y = t[3]
     assert x.shape == (32,) and torch.equal(x[1:], y[:-1])
+
+
+def test_prefetch_loader_same_batches_early_break_and_errors():
+    import threading
+    from distributedpytorch_amd.data import BatchLoader, PrefetchLoader, SyntheticImageDataset
+    ds = SyntheticImageDataset(50, (1, 8, 8), 10, seed=5)
+    plain = BatchLoader(ds, 16, shuffle=True, seed=3)
+    pre = PrefetchLoader(BatchLoader(ds, 16, shuffle=True, seed=3), None, depth=2)
+    assert len(pre) == len(plain) == 4 and pre.batch_size == 16 and pre.dataset is ds
+    for epoch in range(2):
+        plain.set_epoch(epoch); pre.set_epoch(epoch)
+        a, b = list(plain), list(pre)
+        assert len(a) == len(b) == 4 and b[-1][0].shape[0] == 2          # ragged last batch kept
+        for (xa, ya), (xb, yb) in zip(a, b):
+            assert torch.equal(xa, xb) and torch.equal(ya, yb)
+    multi = PrefetchLoader(BatchLoader(ds, 16, shuffle=True, seed=3), None, depth=2, workers=3)
+    for epoch in range(2):
+        plain.set_epoch(epoch); multi.set_epoch(epoch)
+        for (xa, ya), (xb, yb) in zip(list(plain), list(multi)):         # several batches in flight, order kept
+            assert torch.equal(xa, xb) and torch.equal(ya, yb)
+    before = threading.active_count()
+    for i, _ in enumerate(multi):
+        if i == 0:
+            break
+    for i, _ in enumerate(pre):                                          # leaving early stops the producer
+        if i == 1:
+            break
+    assert threading.active_count() <= before
+
+    class Broken:
+        def __len__(self):
+            return 3
+
+        def __iter__(self):
+            yield torch.zeros(1), torch.zeros(1)
+            raise RuntimeError("disk on fire")
+
+    it = iter(PrefetchLoader(Broken()))
+    next(it)
+    with pytest.raises(RuntimeError, match="disk on fire"):
+        next(it)

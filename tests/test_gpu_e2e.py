@@ -438,3 +438,19 @@ def test_pipeline_stages_share_the_gpu_and_match_the_unsplit_cpu_model(tmp_path,
                     g = got[n if b - a == 1 else f"{li - a}.{n}"]
                     num += float((g - p.grad.cpu()).pow(2).sum()); den += float(p.grad.pow(2).sum())
         assert (num / den) ** 0.5 < 0.05, (num / den) ** 0.5
+
+
+@pytest.mark.parametrize("workers", [1, 3])
+def test_prefetch_loader_delivers_the_same_batches_on_the_device(workers):
+    """Pinned staging + copy-stream H2D ahead of the consumer: same order, same bytes as the in-line loader, usable
+    on the current stream right away (the consumer waits on the copy's event)."""
+    from distributedpytorch_amd.data import BatchLoader, PrefetchLoader, SyntheticImageDataset
+    ds = SyntheticImageDataset(70, (3, 32, 32), 10, seed=9)
+    plain = BatchLoader(ds, 16, shuffle=True, seed=2)
+    pre = PrefetchLoader(BatchLoader(ds, 16, shuffle=True, seed=2), torch.device(DEV, 0), depth=2, workers=workers)
+    sums = []
+    for (xa, ya), (xb, yb) in zip(plain, pre):
+        assert xb.is_cuda and yb.is_cuda
+        sums.append((xb * 2).sum())                       # consumed on the compute stream immediately
+        assert torch.equal(xa, xb.cpu()) and torch.equal(ya, yb.cpu())
+    assert len(sums) == 5
