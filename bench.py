@@ -50,6 +50,7 @@ def parse():
     p.add_argument("--micro-batches", type=int, default=8)
     p.add_argument("--schedule", default="1f1b")
     p.add_argument("--no-sink", action="store_true")
+    p.add_argument("--shard-optimizer", action="store_true", help="ZeRO stage 1: optimizer state sharded over the DP ranks")
     p.add_argument("--backend", default="auto")
     return p.parse_args()
 
@@ -148,8 +149,13 @@ def main():
             cfg = {"model": "mnist_cnn", "global_batch": batch * world, "image": "1x28x28"}
 
         dp = DataParallel(model, communicator, bucket_mb=args.bucket_mb, first_bucket_mb=args.first_bucket_mb,
-                          use_sink=not args.no_sink, use_lp=use_lp)
-        opt = FusedSGD(dp.flat, lr=lr, momentum=momentum, weight_decay=wd)
+                          use_sink=not args.no_sink, use_lp=use_lp, shard_optimizer=args.shard_optimizer)
+        if args.shard_optimizer:
+            from distributedpytorch_amd.optim import ShardedSGD
+            opt = ShardedSGD(dp, lr=lr, momentum=momentum, weight_decay=wd)
+            cfg["optimizer_state"] = "sharded (ZeRO-1)"
+        else:
+            opt = FusedSGD(dp.flat, lr=lr, momentum=momentum, weight_decay=wd)
         opt.grad_scale = dp.grad_scale
 
         graphed = None

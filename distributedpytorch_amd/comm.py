@@ -249,6 +249,22 @@ class Communicator:
         work.wait()
         return None
 
+    def reduce(self, tensor: torch.Tensor, dst: int, async_op: bool = False):
+        """Sum onto group rank ``dst`` (in place there; other ranks' buffers are left in an unspecified state).
+        The sharded optimizer's gradient path (parallel/dp.py, ``shard_optimizer``)."""
+        if self.world_size == 1:
+            return _DoneWork() if async_op else None
+        if self._staged(tensor) and not _GLOO_NATIVE_DEVICE:
+            host = tensor.cpu()
+            inner = dist.reduce(host, dst=self.to_global(dst), group=self.group, async_op=True)
+            work = _StagedWork(inner, host, tensor if self.rank == dst else None)
+        else:
+            work = dist.reduce(tensor, dst=self.to_global(dst), group=self.group, async_op=True)
+        if async_op and not _SYNC_DEBUG:
+            return work
+        work.wait()
+        return _DoneWork() if async_op else None
+
     def reduce_scatter(self, output: torch.Tensor, input: torch.Tensor, async_op: bool = False):
         if self.world_size == 1:
             output.copy_(input)

@@ -61,6 +61,7 @@ class TrainConfig:
     # ---- engine ----
     bucket_mb: float = 32.0
     first_bucket_mb: float = 4.0
+    shard_optimizer: bool = False  # ZeRO stage 1 (optim.ShardedSGD)
     micro_batches: int = 1
     schedule: str = "1f1b"
     stages: int = 2
@@ -127,6 +128,7 @@ def dp_parser() -> argparse.ArgumentParser:
     p.add_argument("--batch-size", default=128, type=int, help="GLOBAL batch (reference fixes 128, DP.py:109)")
     p.add_argument("--bucket-mb", default=32.0, type=float)
     p.add_argument("--first-bucket-mb", default=4.0, type=float)
+    p.add_argument("--shard-optimizer", action="store_true", help="optimizer state sharded over the ranks (ZeRO stage 1)")
     return p
 
 
@@ -169,6 +171,7 @@ def config_from_args(args: argparse.Namespace, mode: str) -> TrainConfig:
     if mode == "dp":
         cfg.bucket_mb = args.bucket_mb
         cfg.first_bucket_mb = args.first_bucket_mb
+        cfg.shard_optimizer = args.shard_optimizer
     else:
         cfg.micro_batches = args.micro_batches
         cfg.schedule = args.schedule

@@ -110,6 +110,92 @@ class FusedSGD:
             self.momentum_buf[off:off + p.numel()].copy_(st["momentum_buffer"].reshape(-1).to(f.device))
 
 
+class ShardedSGD(FusedSGD):
+    """SGD-momentum with the optimizer state sharded over the data-parallel ranks (ZeRO stage 1) - for
+    ``DataParallel(..., shard_optimizer=True)``.  Rank r holds the momentum of its shard only and runs the fused
+    update kernel over that slice of the flat buffers (same kernel, same per-segment weight decay); the updated fp32
+    parameters of every shard are then broadcast from their owner and the bf16 shadows re-derived locally.
+    ``state_dict()`` gathers the shards so the checkpoint is the same stock ``torch.optim.SGD`` layout as FusedSGD's.
+    """
+
+    def __init__(self, dp, lr: float = 0.01, momentum: float = 0.0, weight_decay: float = 0.0, nesterov: bool = False,
+                 no_decay: Optional[Callable[[str, torch.Tensor], bool]] = _no_decay):
+        if dp.shards is None:
+            raise ValueError("ShardedSGD needs DataParallel(..., shard_optimizer=True)")
+        self.dp, self.comm = dp, dp.comm
+        self.lo, self.hi = dp.shards[dp.comm.rank], dp.shards[dp.comm.rank + 1]
+        super().__init__(dp.flat, lr, momentum, weight_decay, nesterov, no_decay)
+        self.grad_scale = dp.grad_scale
+        if self.momentum_buf is not None:                      # the parent allocated a full-size buffer: keep 1/N of it
+            self.momentum_buf = torch.zeros(self.hi - self.lo, dtype=torch.float32, device=self.flat.device)
+        # the weight-decay runs clipped to this shard, relative to its start
+        self.shard_segments = [(max(a, self.lo) - self.lo, min(b, self.hi) - self.lo, w)
+                               for a, b, w in self.segments if max(a, self.lo) < min(b, self.hi)]
+
+    @torch.no_grad()
+    def step(self, grad_scale: Optional[float] = None, zero_grad: bool = True) -> None:
+        f = self.flat
+        gs = self.grad_scale if grad_scale is None else grad_scale
+        lo, hi = self.lo, self.hi
+        if hi > lo:
+            p, g = f.master[lo:hi], f.grad[lo:hi]
+            if f.device.type == "cuda":
+                from .ops import _ext, side
+                side.join(f.device)
+                C = _ext.load()
+                if len(self.shard_segments) > 1 and self._seg_ends is None:
+                    self._seg_ends = torch.tensor([b for _, b, _ in self.shard_segments], dtype=torch.int64, device=f.device)
+                    self._seg_wd = torch.tensor([w for _, _, w in self.shard_segments], dtype=torch.float32, device=f.device)
+                C.sgd_momentum(p, g, self.momentum_buf, None, self.lr, self.momentum,
+                               self.shard_segments[0][2], gs, False, self.nesterov, self._seg_ends, self._seg_wd)
+            else:
+                for a, b, wd in self.shard_segments:
+                    d = g[a:b] * gs
+                    if wd != 0.0:
+                        d = d + wd * p[a:b]
+                    if self.momentum_buf is not None:
+                        m = self.momentum_buf[a:b]
+                        m.mul_(self.momentum).add_(d)
+                        d = d + self.momentum * m if self.nesterov else m
+                    p[a:b].add_(d, alpha=-self.lr)
+        # updated parameters back to everyone: one broadcast per shard, all in flight together
+        works = [self.comm.broadcast(f.master[self.dp.shards[r]:self.dp.shards[r + 1]], src=r, async_op=True)
+                 for r in range(self.comm.world_size) if self.dp.shards[r + 1] > self.dp.shards[r]]
+        if zero_grad:
+            f.grad.zero_()
+        for w in works:
+            w.wait()
+        f.refresh_lp()                  # bf16 shadows (and the transposed filter twins) from the gathered masters
+        self.steps += 1
+
+    def _full_momentum(self) -> Optional[torch.Tensor]:
+        if self.momentum_buf is None:
+            return None
+        full = torch.zeros(self.flat.total, dtype=torch.float32, device=self.flat.device)
+        full[self.lo:self.hi].copy_(self.momentum_buf)
+        for r in range(self.comm.world_size):
+            a, b = self.dp.shards[r], self.dp.shards[r + 1]
+            if b > a:
+                self.comm.broadcast(full[a:b], src=r)
+        return full
+
+    def state_dict(self) -> Dict:
+        """Collective: every rank must call it (the momentum shards are gathered)."""
+        own = self.momentum_buf
+        self.momentum_buf = self._full_momentum()
+        try:
+            return super().state_dict()
+        finally:
+            self.momentum_buf = own
+
+    def load_state_dict(self, sd: Dict) -> None:
+        own = self.momentum_buf
+        self.momentum_buf = torch.zeros(self.flat.total, dtype=torch.float32, device=self.flat.device)
+        super().load_state_dict(sd)
+        shard = self.momentum_buf[self.lo:self.hi].clone()
+        self.momentum_buf = shard if (own is not None or self.momentum != 0.0) else None
+
+
 class FusedAdamW:
     """AdamW over the flat buffer (used for the GPT-2 configuration when asked)."""
 

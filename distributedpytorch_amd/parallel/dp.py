@@ -32,16 +32,39 @@ from ..ops import sink as _sink
 from .flat import Bucket, FlatParams
 
 
+def shard_bounds(total: int, world_size: int, align: int = 64) -> List[int]:
+    """``world_size + 1`` offsets cutting ``[0, total)`` into contiguous, ``align``-element aligned, near-equal shards
+    (the last one takes the remainder; trailing shards may be empty for tiny models)."""
+    per = -(-total // world_size)
+    per = -(-per // align) * align
+    return [min(total, r * per) for r in range(world_size)] + [total]
+
+
+class _Works:
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        return True
+
+
 class DataParallel:
     def __init__(self, module: nn.Module, comm: Optional[_comm.Communicator] = None, flat: Optional[FlatParams] = None,
                  bucket_mb: float = 32.0, first_bucket_mb: float = 4.0, broadcast_params: bool = True,
-                 use_sink: bool = True, use_lp: bool = True):
+                 use_sink: bool = True, use_lp: bool = True, shard_optimizer: bool = False):
         self.module = module
         self.comm = comm if comm is not None else _comm.Communicator()
         self.flat = flat if flat is not None else FlatParams(module, use_lp=use_lp)
         self.world_size = self.comm.world_size
         self.grad_scale = 1.0 / self.world_size
         self.buckets: List[Bucket] = self.flat.plan_buckets(int(bucket_mb * 2 ** 20), int(first_bucket_mb * 2 ** 20))
+        # shard_optimizer (ZeRO stage 1; not in the reference): rank r owns flat[shards[r]:shards[r+1]) - its gradient
+        # is reduced ONTO r only, r alone keeps optimizer state for it and updates it, and the updated parameters are
+        # broadcast back (optim.ShardedSGD).  Same bytes on the links as the all-reduce it replaces (a reduce plus a
+        # broadcast per shard), 1/N of the optimizer's memory and HBM traffic per GPU.
+        self.shards: Optional[List[int]] = shard_bounds(self.flat.total, self.world_size) if shard_optimizer else None
         self._bucket_of: Dict[int, Bucket] = {}
         self._uses: Dict[int, int] = {}
         for b in self.buckets:
@@ -133,7 +156,15 @@ class DataParallel:
         view = self.flat.grad[b.start:b.end]
         if view.is_cuda:
             _side.join(view.device)       # weight gradients are produced on the side stream (ops/side.py)
-        b.work = self.comm.all_reduce(view, async_op=True)
+        if self.shards is not None and self.world_size > 1:
+            works = []
+            for r in range(self.world_size):            # every rank walks the owners in the same order
+                lo, hi = max(b.start, self.shards[r]), min(b.end, self.shards[r + 1])
+                if lo < hi:
+                    works.append(self.comm.reduce(self.flat.grad[lo:hi], dst=r, async_op=True))
+            b.work = _Works(works)
+        else:
+            b.work = self.comm.all_reduce(view, async_op=True)
         self._launched.append(b)
         self.stats["allreduce_calls"] += 1
         self.stats["allreduce_bytes"] += view.numel() * 4

@@ -19,7 +19,7 @@ from . import data as ddata
 from . import metrics as dmetrics
 from .checkpoint import load_checkpoint, save_checkpoint
 from .config import TrainConfig
-from .optim import FusedSGD
+from .optim import FusedSGD, ShardedSGD
 from .parallel.dp import DataParallel
 from .parallel.flat import FlatParams
 from .parallel.pp import PipelineStage, build_stage_module, partition_balanced, param_costs
@@ -81,8 +81,11 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
         loader, bsz = ddata.partition_dataset(dataset, comm.rank, comm.world_size, cfg.batch_size, cfg.seed, device,
                                               workers=max(1, cfg.workers))
         dp = DataParallel(model, comm, bucket_mb=cfg.bucket_mb, first_bucket_mb=cfg.first_bucket_mb,
-                          use_lp=use_lp)                 # ... and a broadcast from rank 0 for safety
-        opt = FusedSGD(dp.flat, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
+                          use_lp=use_lp, shard_optimizer=cfg.shard_optimizer)   # ... and a broadcast from rank 0 for safety
+        if cfg.shard_optimizer:
+            opt = ShardedSGD(dp, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
+        else:
+            opt = FusedSGD(dp.flat, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
         opt.grad_scale = dp.grad_scale                   # the `/= world_size` of DP.py:129, fused
         start_epoch = 0
         if cfg.resume:
@@ -107,7 +110,7 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                 epoch_loss += loss.detach()              # stays on device: no host sync (DP.py:153)
                 loss.backward()
                 dp.finish()                              # bucketed all-reduce, overlapped with backward
-                if cfg.sync_debug:
+                if cfg.sync_debug and not cfg.shard_optimizer:   # (sharded: only the owner holds a shard's reduced gradient)
                     dmetrics.check_reduced_gradients(dp.flat, comm)
                 opt.step()                               # fused: scale, momentum, update, bf16 shadow, zero grad
                 meter.update(x.shape[0])

@@ -62,8 +62,13 @@ def dp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, buc
     x, y = _data(shape, classes, n_global)
     per = n_global // world_size
     xs, ys = x[global_rank * per:(global_rank + 1) * per].to(device), y[global_rank * per:(global_rank + 1) * per].to(device)
-    dp = DataParallel(model, comm, bucket_mb=bucket_kb / 1024.0, first_bucket_mb=bucket_kb / 4096.0, use_lp=(model_name != "mnist"))
-    opt = FusedSGD(dp.flat, lr=0.05, momentum=0.5)
+    dp = DataParallel(model, comm, bucket_mb=bucket_kb / 1024.0, first_bucket_mb=bucket_kb / 4096.0, use_lp=(model_name != "mnist"),
+                      shard_optimizer=(mode == "zero"))
+    if mode == "zero":                       # optimizer state sharded over the ranks (optim.ShardedSGD)
+        from ..optim import ShardedSGD
+        opt = ShardedSGD(dp, lr=0.05, momentum=0.5, weight_decay=1e-3)
+    else:
+        opt = FusedSGD(dp.flat, lr=0.05, momentum=0.5, weight_decay=1e-3 if mode == "zero_ref" else 0.0)
     opt.grad_scale = dp.grad_scale
     losses = []
     for s in range(steps):
@@ -76,7 +81,7 @@ def dp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, buc
             loss = loss_fn(model, xs, ys)
             loss.backward()
             dp.finish()
-        if s == 0:
+        if s == 0 and mode != "zero":        # (sharded: a rank only holds the reduced gradient of its own shard)
             if device.type == "cuda":
                 torch.cuda.synchronize()
             g = dp.flat.grad.clone().cpu() * dp.grad_scale
@@ -86,7 +91,8 @@ def dp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, buc
         opt.step()
         losses.append(float(loss.detach()))
     torch.save({"losses": losses, "params": {n: p.detach().cpu().clone() for n, p in model.named_parameters()},
-                "buckets": len(dp.buckets), "calls": dp.stats["allreduce_calls"]},
+                "buckets": len(dp.buckets), "calls": dp.stats["allreduce_calls"], "opt": opt.state_dict(),
+                "momentum_numel": 0 if opt.momentum_buf is None else opt.momentum_buf.numel()},
                os.path.join(out_dir, f"final_{global_rank}.pt"))
     comm.barrier()
     dcomm.destroy_process_group()
