@@ -231,3 +231,46 @@ class FusedAdamW:
             f.master.addcdiv_(mh, vh.sqrt().add_(self.eps), value=-self.lr)
             if zero_grad:
                 f.grad.zero_()
+
+
+# ---------------------------------------------------------------------------- training-loop utilities
+@torch.no_grad()
+def clip_grad_norm(flat: FlatParams, max_norm: float, grad_scale: float = 1.0, shard=None, comm=None) -> torch.Tensor:
+    """Global-norm gradient clipping over the flat gradient buffer, after ``DataParallel.finish()`` and before the
+    optimizer step.  The buffer holds the SUM over ranks (the ``1 / world`` lives in the optimizer's ``grad_scale``),
+    so pass that scale: the norm returned (a device scalar - nothing here synchronises the host) is the norm of the
+    mean gradient.  With a sharded optimizer pass ``shard=(lo, hi)`` and the communicator: each rank holds the reduced
+    gradient of its shard only, the squared norms are summed across ranks.  Not in the reference (constant-lr SGD,
+    DP.py:143); GPT-2 training needs it."""
+    g = flat.grad if shard is None else flat.grad[shard[0]:shard[1]]
+    sq = torch.linalg.vector_norm(g).square() if g.numel() else torch.zeros((), device=flat.grad.device)
+    if shard is not None and comm is not None and comm.world_size > 1:
+        sq = sq.reshape(1)
+        comm.all_reduce(sq)
+        sq = sq[0]
+    norm = sq.sqrt() * grad_scale
+    coef = (max_norm / (norm + 1e-6)).clamp(max=1.0)
+    g.mul_(coef)
+    return norm
+
+
+class WarmupCosine:
+    """Learning-rate schedule: linear warm-up to ``base_lr`` over ``warmup`` steps, cosine decay to ``min_lr`` at
+    ``total`` steps.  ``sched.apply(opt, step)`` sets ``opt.lr`` (the fused kernels take the rate as a launch argument,
+    so changing it costs nothing)."""
+
+    def __init__(self, base_lr: float, warmup: int, total: int, min_lr: float = 0.0):
+        self.base_lr, self.warmup, self.total, self.min_lr = float(base_lr), int(warmup), int(total), float(min_lr)
+
+    def __call__(self, step: int) -> float:
+        import math
+        if self.warmup > 0 and step < self.warmup:
+            return self.base_lr * (step + 1) / self.warmup
+        if step >= self.total:
+            return self.min_lr
+        t = (step - self.warmup) / max(1, self.total - self.warmup)
+        return self.min_lr + 0.5 * (self.base_lr - self.min_lr) * (1.0 + math.cos(math.pi * t))
+
+    def apply(self, opt, step: int) -> float:
+        opt.lr = self(step)
+        return opt.lr

@@ -70,3 +70,28 @@ def test_plan_buckets():
     assert [x.start for x in b][0] == 0 and b[-1].end == cur
     assert all(b[i].end == b[i + 1].start for i in range(len(b) - 1))
     assert sorted(sum((x.param_indices for x in b), [])) == order
+
+
+def test_clip_grad_norm_and_lr_schedule():
+    import math
+    import torch
+    from distributedpytorch_amd.optim import FusedSGD, WarmupCosine, clip_grad_norm
+    from distributedpytorch_amd.parallel.flat import FlatParams
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    flat = FlatParams(m, use_lp=False)
+    m(torch.randn(5, 8)).square().sum().backward()
+    ref = torch.nn.utils.clip_grad_norm_([p for p in m.parameters()], max_norm=0.1)      # stock, on the same views
+    # undo (the stock call scaled in place), then ours with world-size-2 bookkeeping: buffer = 2 x mean gradient
+    flat.grad.mul_(float(ref) / 0.1 if float(ref) > 0.1 else 1.0)
+    before = flat.grad.clone()
+    flat.grad.mul_(2.0)
+    norm = clip_grad_norm(flat, 0.1, grad_scale=0.5)
+    assert abs(float(norm) - float(before.norm())) < 1e-5
+    assert abs(float(flat.grad.norm()) * 0.5 - 0.1) < 1e-4                  # the mean gradient now has norm 0.1
+    sched = WarmupCosine(1.0, warmup=4, total=12, min_lr=0.1)
+    assert [round(sched(s), 4) for s in range(4)] == [0.25, 0.5, 0.75, 1.0]
+    assert abs(sched(4) - 1.0) < 1e-9 and abs(sched(8) - (0.1 + 0.45 * (1 + math.cos(math.pi * 0.5)))) < 1e-9
+    assert sched(12) == 0.1 and sched(100) == 0.1
+    opt = FusedSGD(flat, lr=1.0)
+    assert sched.apply(opt, 1) == 0.5 and opt.lr == 0.5
