@@ -31,7 +31,7 @@ struct Guard {
 // `addend` (bf16, the output's shape): y = conv(x) + bias + addend - a residual connection in the GEMM epilogue.
 std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias, int64_t stride,
                                int64_t pad, int64_t act, bool want_stats, const c10::optional<Tensor>& stats_buf,
-                               const c10::optional<Tensor>& addend) {
+                               const c10::optional<Tensor>& addend, bool gelu_twin) {
     CHECK_BF16(x); CHECK_BF16(w);
     TORCH_CHECK(x.dim() == 4 && w.dim() == 4, "conv_fprop: x and w must be 4-D (NHWC / KRSC)");
     const int64_t N = x.size(0), H = x.size(1), W = x.size(2), C = x.size(3);
@@ -76,8 +76,15 @@ std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::opti
     }
     a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.Ho = Ho; a.Wo = Wo;
     a.stride = stride; a.pad = pad; a.mode = 0; a.act = act;
+    Tensor y_act;
+    if (gelu_twin) {      // second output gelu_tanh(y): the next GEMM's operand, y itself stays for the GELU's backward
+        TORCH_CHECK(!want_stats && act == 0, "conv_fprop: gelu_twin goes with a linear epilogue and no statistics");
+        y_act = torch::empty_like(y);
+        a.y_act = y_act.data_ptr();
+    }
     dpa::conv_igemm(a, cur_stream());
     if (want_stats) return {y, stats};
+    if (gelu_twin) return {y, y_act};
     return {y};
 }
 
@@ -782,7 +789,7 @@ void bind_rccl(pybind11::module_& m);         // rccl_comm.cpp
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "distributedpytorch_amd gfx950 kernels";
     m.def("conv_fprop", &conv_fprop, py::arg("x"), py::arg("w"), py::arg("bias"), py::arg("stride"), py::arg("pad"), py::arg("act"),
-          py::arg("want_stats"), py::arg("stats_buf"), py::arg("addend") = py::none());
+          py::arg("want_stats"), py::arg("stats_buf"), py::arg("addend") = py::none(), py::arg("gelu_twin") = false);
     m.def("conv_dgrad", &conv_dgrad, py::arg("dy"), py::arg("wt"), py::arg("H"), py::arg("W"), py::arg("stride"), py::arg("pad"),
           py::arg("addend"), py::arg("addend_mask"), py::arg("bn_x") = py::none(), py::arg("bn_mask") = py::none(),
           py::arg("bn_stats") = py::none(), py::arg("gelu_x") = py::none());

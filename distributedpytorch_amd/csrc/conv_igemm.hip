@@ -625,6 +625,13 @@ __global__ __launch_bounds__(256, igemm_waves_per_simd(WP, ONE, STG)) void conv_
                 v = pack8(f);
             }
             *(uint4*)(yg + (size_t)eoff[pss]) = v;
+            if (MODE == 0 && a.y_act != nullptr) {     // the activated twin, from the bf16 values just stored
+                float f[8];
+                unpack8(v, f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = gelu_tanh(f[j]);
+                *(uint4*)((unsigned short*)a.y_act + (size_t)eoff[pss]) = pack8(f);
+            }
         }
     }
 }

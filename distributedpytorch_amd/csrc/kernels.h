@@ -42,6 +42,8 @@ struct ConvArgs {
     unsigned char* ep_mask_out;
     float* ep_stats; int ep_stats_rows;
     //   epi 5 (dgrad, stride 1): y = dgrad * gelu'(ep_src), ep_src = the input of the tanh-GELU in front of this layer
+    void* y_act;        // fprop, epi 0: optional SECOND output gelu_tanh(y) (bf16, y's shape) - the activated copy the next
+                        // GEMM reads while y itself is kept for the GELU's backward; nullptr = none
 };
 void conv_igemm(const ConvArgs& a, hipStream_t st);
 int conv_stats_rows(long M);  // replica rows of the stats buffer

@@ -2,6 +2,7 @@
 // Memory-bound: one 64-lane wave per row, 16 B (8 bf16) per lane, wave shuffles
 // for the row reductions; parameter gradients are reduced per block in LDS and
 // written as partial rows (no atomics), then folded by reduce_partials.
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
@@ -204,7 +205,10 @@ inline int grid_for(long n) { long b = (n + 255) / 256; if (b > 4096) b = 4096; 
 
 int layernorm_partial_rows(long rows) {
     long b = (rows + 3) / 4;
-    if (b > 512) b = 512;      // 2 workgroups per CU; every extra one is another partial row to fold
+    // one workgroup per CU.  Measured in the GPT-2 step (8192 x 768, fold on the side stream), tok/s: 128 blocks 580k,
+    // 256: 624.6k, 384: 617k, 512: 620k, 1024: 616k, 2048: 599k - every extra block is another partial row to fold
+    static const long cap = [] { const char* e = getenv("DPA_LN_ROWS"); return e ? atol(e) : 256L; }();
+    if (b > cap) b = cap;
     if (b < 1) b = 1;
     return (int)b;
 }

@@ -11,6 +11,7 @@ cross-entropy is fused and its backward runs in place over the logits.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import List
 
@@ -45,6 +46,10 @@ class Attention(nn.Module):
         return self.c_proj(ops.causal_attention(self.c_attn(x), self.n_head), residual=residual)
 
 
+# opt-in: measured 1 % SLOWER than the elementwise GELU pass it removes (599.0k vs 604.7k tok/s, docs/DESIGN.md §6)
+_GELU_TWIN = os.environ.get("DPA_GELU_TWIN", "0") == "1"
+
+
 class MLP(nn.Module):
     def __init__(self, cfg: GPT2Config):
         super().__init__()
@@ -52,7 +57,12 @@ class MLP(nn.Module):
         self.c_proj = Linear(4 * cfg.n_embd, cfg.n_embd, init_std=0.02 / math.sqrt(2 * cfg.n_layer))
 
     def forward(self, x, residual=None):
-        return self.c_proj(self.c_fc(x), residual=residual, pre_gelu=True)     # gelu inside: its backward is an epilogue
+        # gelu inside c_proj: its backward is an epilogue of c_proj's input-gradient GEMM.  With DPA_GELU_TWIN=1 c_fc's
+        # epilogue also writes gelu(h) beside h, so the forward elementwise pass disappears too
+        if _GELU_TWIN:
+            h, act = self.c_fc(x, gelu_twin=True)
+            return self.c_proj(h, residual=residual, pre_gelu=True, gelu_act=act)
+        return self.c_proj(self.c_fc(x), residual=residual, pre_gelu=True)
 
 
 class Block(nn.Module):

@@ -116,10 +116,18 @@ class Linear(nn.Module):
         self.weight_lp: Optional[torch.Tensor] = None
         self.weight_lp_t: Optional[torch.Tensor] = None    # [in, out] twin for the input gradient, kept by FlatParams
 
-    def forward(self, x, keep_padding: bool = False, residual=None, pre_gelu: bool = False):
+    def forward(self, x, keep_padding: bool = False, residual=None, pre_gelu: bool = False, gelu_twin: bool = False,
+                gelu_act=None):
+        """``gelu_twin``: returns ``(y, gelu(y))`` (second output of the same GEMM epilogue; None off the GPU);
+        ``pre_gelu`` + ``gelu_act``: ``y = gelu(x) W^T + b`` where ``gelu_act`` is that already-computed gelu(x)."""
         if residual is not None and self.out_padded != self.out_features:
-            return self.forward(x, keep_padding, None, pre_gelu) + residual      # padded outputs: no fused residual
-        y = ops.linear(x, self.weight, self.weight_lp, self.bias, self.weight_lp_t, residual, pre_gelu)
+            return self.forward(x, keep_padding, None, pre_gelu, False, gelu_act) + residual    # padded outputs: no fused residual
+        if gelu_twin and self.out_padded != self.out_features:
+            return self.forward(x, keep_padding, residual, pre_gelu, False, gelu_act), None
+        y = ops.linear(x, self.weight, self.weight_lp, self.bias, self.weight_lp_t, residual, pre_gelu,
+                       gelu_twin=gelu_twin, gelu_act=gelu_act)
+        if gelu_twin:
+            return y
         if not keep_padding and self.out_padded != self.out_features:
             y = y[..., : self.out_features]
         return y

@@ -35,21 +35,23 @@ def _lp(weight: torch.Tensor, weight_lp: Optional[torch.Tensor]) -> torch.Tensor
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, weight_lp, bias, stride, pad, want_stats, act, wshape, stats_buf=None, weight_lp_t=None,
-                residual=None, pre_gelu=False):
+                residual=None, pre_gelu=False, gelu_twin=False, gelu_act=None):
         C = _ext.load()
         w = _lp(weight, weight_lp).view(wshape)   # KRSC view (a Linear weight [out,in] is K,1,1,C)
         ctx.pre_gelu = pre_gelu
         if pre_gelu:                              # y = layer(gelu(x)): the GELU's backward rides the dgrad epilogue
             ctx.gelu_in = x
-            x = C.ew2(x, x, 3)
-        outs = C.conv_fprop(x, w, bias, stride, pad, act, want_stats, stats_buf, residual)   # + residual in the epilogue
+            # gelu(x) already exists when the layer that produced x wrote it beside x (gelu_twin): no elementwise pass
+            x = gelu_act if gelu_act is not None else C.ew2(x, x, 3)
+        # + residual in the epilogue; gelu_twin: second output gelu(y) for the next layer (second slot of the result)
+        outs = C.conv_fprop(x, w, bias, stride, pad, act, want_stats, stats_buf, residual, gelu_twin)
         ctx.has_residual = residual is not None
         ctx.save_for_backward(x, w)
         ctx.weight = weight
         ctx.bias = bias
         ctx.geom = (stride, pad, act)
         ctx.wt = weight_lp_t        # optimizer-maintained [C,R,S,K] twin (FlatParams), or None
-        if want_stats:
+        if want_stats or gelu_twin:
             ctx.mark_non_differentiable(outs[1])
             return outs[0], outs[1]
         return outs[0], None
@@ -92,7 +94,7 @@ class _ConvFn(torch.autograd.Function):
             _sink.ready(bias)
         # the residual connection passes the gradient through unchanged
         dres = dy if (ctx.has_residual and ctx.needs_input_grad[11]) else None
-        return dx, dw, None, db, None, None, None, None, None, None, None, dres, None
+        return dx, dw, None, db, None, None, None, None, None, None, None, dres, None, None, None
 
 
 def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, weight_lp: Optional[torch.Tensor] = None,
@@ -159,11 +161,14 @@ class _PlainLinearFn(torch.autograd.Function):
 
 def linear(x: torch.Tensor, weight: torch.Tensor, weight_lp: Optional[torch.Tensor] = None,
            bias: Optional[torch.Tensor] = None, weight_lp_t: Optional[torch.Tensor] = None,
-           residual: Optional[torch.Tensor] = None, pre_gelu: bool = False, plain: bool = False) -> torch.Tensor:
+           residual: Optional[torch.Tensor] = None, pre_gelu: bool = False, plain: bool = False,
+           gelu_twin: bool = False, gelu_act: Optional[torch.Tensor] = None):
     """``y = x @ weight^T + bias (+ residual)`` with ``weight [out, in]``; any leading dims on ``x``.
     ``weight_lp_t`` is the optional bf16 ``[in, out]`` twin the input gradient multiplies by; ``residual`` (the
     output's shape) is added in the GEMM epilogue; ``pre_gelu``: ``y = gelu_tanh(x) @ weight^T ...`` with the GELU's
-    backward folded into the input-gradient GEMM's epilogue.  ``plain``: the caller fuses nothing into this GEMM and
+    backward folded into the input-gradient GEMM's epilogue; ``gelu_twin``: returns ``(y, gelu_tanh(y))``, the second
+    written by the same epilogue (None off the GPU) - hand it to the next layer as ``gelu_act`` with ``pre_gelu``.
+    ``plain``: the caller fuses nothing into this GEMM and
     it is large (the LM head) - forward and input gradient may go to the library GEMM (see _PlainLinearFn)."""
     if _ext.use_hip(x):
         lead = x.shape[:-1]
@@ -174,9 +179,14 @@ def linear(x: torch.Tensor, weight: torch.Tensor, weight_lp: Optional[torch.Tens
         x4 = x.reshape(-1, 1, 1, cin)
         wt = None if weight_lp_t is None else weight_lp_t.view(cin, 1, 1, cout)
         r4 = None if residual is None else residual.contiguous().reshape(-1, 1, 1, cout)
-        y, _ = _ConvFn.apply(x4.contiguous(), weight, weight_lp, bias, 1, 0, False, 0, (cout, 1, 1, cin), None, wt, r4, pre_gelu)
+        ga = None if gelu_act is None else gelu_act.reshape(-1, 1, 1, cin)
+        y, twin = _ConvFn.apply(x4.contiguous(), weight, weight_lp, bias, 1, 0, False, 0, (cout, 1, 1, cin), None, wt, r4, pre_gelu,
+                                gelu_twin, ga)
+        if gelu_twin:
+            return y.reshape(*lead, cout), twin.reshape(*lead, cout)
         return y.reshape(*lead, cout)
     if pre_gelu:
         x = F.gelu(x, approximate="tanh")
     y = F.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
-    return y if residual is None else y + residual
+    y = y if residual is None else y + residual
+    return (y, None) if gelu_twin else y

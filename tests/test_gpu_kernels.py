@@ -352,6 +352,36 @@ def test_plain_linear_library_path_matches_fp32_reference_and_own_kernels():
         _close(dw, dwr, 2e-2, 2e-2, "plain linear dw")
 
 
+def test_gelu_twin_output_equals_the_elementwise_pass():
+    """conv_fprop(gelu_twin=True): the epilogue's second output is gelu_tanh of the bf16 values it stores - bit-equal
+    to the elementwise kernel it replaces - and the MLP built on it matches the fp32 expression."""
+    from distributedpytorch_amd import ops
+    C_ = _C()
+    M, K, N = 200, 64, 136
+    x = _rand_bf16(M, 1, 1, K, seed=71); w = _rand_bf16(N, 1, 1, K, scale=0.2, seed=72)
+    bias = torch.randn(N, device=DEV) * 0.1
+    y, act = C_.conv_fprop(x, w, bias, 1, 0, 0, False, None, None, True)
+    y0 = C_.conv_fprop(x, w, bias, 1, 0, 0, False, None)[0]
+    assert torch.equal(y, y0) and torch.equal(act, C_.ew2(y0, y0, 3))
+    ref = torch.nn.functional.gelu(x.float().view(M, K) @ w.float().view(N, K).t() + bias, approximate="tanh")
+    _close(act.float().view(M, N), ref, 2e-2, 2e-2, "gelu twin")
+    # through ops.linear: (h, gelu(h)) then the consumer with pre_gelu + gelu_act; gradients reach x and both weights
+    xs = _rand_bf16(4, 50, K, seed=73).requires_grad_()
+    w1 = (torch.randn(N, K, device=DEV) * 0.1).requires_grad_(); b1 = torch.zeros(N, device=DEV, requires_grad=True)
+    w2 = (torch.randn(K, N, device=DEV) * 0.1).requires_grad_()
+    h, a = ops.linear(xs, w1, None, b1, gelu_twin=True)
+    out = ops.linear(h, w2, None, None, pre_gelu=True, gelu_act=a)
+    out.float().square().sum().backward()
+    xr = xs.detach().float().requires_grad_(); w1r = w1.detach().clone().requires_grad_(); w2r = w2.detach().clone().requires_grad_()
+    hr = xr @ w1r.to(torch.bfloat16).float().t()
+    outr = torch.nn.functional.gelu(hr, approximate="tanh") @ w2r.to(torch.bfloat16).float().t()
+    outr.square().sum().backward()
+    _close(out.float(), outr, 3e-2, 3e-2, "mlp out")
+    sc = float(w1r.grad.abs().max())
+    _close(w1.grad, w1r.grad, 5e-2, 5e-2 * sc, "dW1"); _close(xs.grad.float(), xr.grad, 5e-2, 5e-2 * float(xr.grad.abs().max()), "dx")
+    _close(w2.grad, w2r.grad, 5e-2, 5e-2 * float(w2r.grad.abs().max()), "dW2")
+
+
 def test_layernorm_backward_deferred_fold_equals_direct():
     """layernorm_bwd(defer_reduce=True) + ln_fold_partials (what ops/norm.py runs on the side stream) adds the same
     parameter gradients as the one-call form."""
