@@ -94,6 +94,7 @@ class Embedding(nn.Module):
         self.wpe = nn.Parameter(torch.randn(cfg.n_positions, cfg.n_embd) * 0.01)
         self.wte_lp = None
         self.wpe_lp = None
+        self._dpa_tie = ("wte", "first")   # pipeline: this matrix also lives in the LM-head stage (parallel/pp.py)
 
     def forward(self, tokens):
         x = ops.embedding(tokens, self.wte, self.wpe, self.wte_lp, self.wpe_lp)
@@ -131,17 +132,20 @@ class GPT2(nn.Module):
 
 
 class _LMHead(nn.Module):
-    """ln_f + tied head as a pipeline unit (shares ``wte`` with the embedding stage; only
-    valid when both live on the same stage or the tie is dropped)."""
+    """ln_f + tied head as a pipeline unit.  ``wte`` is the embedding's Parameter object: on one stage the two uses
+    share it by reference; when the embedding and the head land on different pipeline stages each stage holds a copy
+    (identical at start: every rank builds the model from the same seed) and the pipeline engine sums the two stages'
+    gradients of it every step (``_dpa_tie``, parallel/pp.py), so both copies take the same update and stay tied."""
 
     def __init__(self, model: GPT2):
         super().__init__()
         self.ln_f = model.ln_f
-        self._model = [model]
+        self.wte = model.emb.wte
+        self.wte_lp = None                 # bound by FlatParams, like Embedding.wte_lp
+        self._dpa_tie = ("wte", "last")
 
     def forward(self, x):
-        m = self._model[0]
-        return ops.linear(self.ln_f(x), m.emb.wte, m.emb.wte_lp, None, plain=True)
+        return ops.linear(self.ln_f(x), self.wte, self.wte_lp, None, plain=True)
 
 
 def gpt2_small() -> GPT2:

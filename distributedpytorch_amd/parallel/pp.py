@@ -128,6 +128,15 @@ class PipelineStage:
         self._out_meta_sent = False
         self._pending_sends: List = []
         self.last_loss: Optional[torch.Tensor] = None
+        # parameters tied across the first and the last stage (GPT-2's wte: embedding + LM head).  A stage holding only
+        # one end exchanges that parameter's gradient with the other end after backward (see _sync_tied)
+        ends: Dict[str, Dict[str, nn.Parameter]] = {}
+        for mod in module.modules():
+            tie = getattr(mod, "_dpa_tie", None)
+            if tie is not None:
+                ends.setdefault(tie[0], {})[tie[1]] = getattr(mod, tie[0])
+        self._tied = [(name, roles["first" if "first" in roles else "last"], "first" if "first" in roles else "last")
+                      for name, roles in sorted(ends.items()) if len(roles) == 1 and self.n_stages > 1]
 
     # ---- shape negotiation: once, trailing dims only (the batch dim comes from the data) ----
     def _send_meta(self, y: torch.Tensor) -> None:
@@ -208,8 +217,27 @@ class PipelineStage:
         self._pending_sends.clear()
         if self.dp is not None:
             self.dp.finish()
+        self._sync_tied()
         self.last_loss = loss_sum
         return loss_sum
+
+    def _sync_tied(self) -> None:
+        """Sum the gradients of a parameter whose two uses sit on the first and the last stage (Megatron's embedding
+        all-reduce, as two transfers over the pipeline group: last -> first, sum, first -> last).  After the replica
+        all-reduce (both are sums, the order is free), before the optimizers - which then apply the same update to both
+        copies."""
+        for _name, p, role in self._tied:
+            g = p.grad
+            if g is None:
+                g = p.grad = torch.zeros_like(p)
+            if role == "last":
+                self.comm.send(g, 0)
+                self.comm.recv(g, 0)
+            else:
+                other = torch.empty_like(g)
+                self.comm.recv(other, self.n_stages - 1)
+                g.add_(other)
+                self.comm.send(g, self.n_stages - 1)
 
     def _run_comm(self, step, sizes, inputs, outputs, grads_in) -> None:
         batch_ops = []

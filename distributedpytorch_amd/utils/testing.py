@@ -41,6 +41,12 @@ def _data(shape, classes, n, seed=7):
     return torch.randn(n, *shape, generator=g), torch.randint(0, classes, (n,), generator=g)
 
 
+def _tokens(n, seq=128, vocab=500, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randint(0, vocab, (n, seq + 1), generator=g)
+    return t[:, :-1].contiguous(), t[:, 1:].contiguous()
+
+
 def dp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, bucket_kb, steps, mode="hooks", backend="gloo"):
     """Each rank takes its shard of ONE global batch; writes reduced grads + params.
     backend "nccl": one GPU per rank over RCCL (multi-GPU boxes only; tests/test_multi_gpu.py);
@@ -116,6 +122,15 @@ def pp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, sta
             layers = mnist.mnist_stages()
             stage_mod = layers[stage]
             loss_fn, shape, classes = mnist.nll_loss, (1, 28, 28), 10
+        elif model_name == "gpt2_tiny":
+            from ..models import gpt2
+            from .. import ops
+            full = gpt2.gpt2_tiny().train()
+            layers = full.pipeline_layers()
+            bounds = partition_balanced(param_costs(layers), stages)
+            stage_mod = build_stage_module(layers, bounds, stage, full)
+            loss_fn = (lambda o, t: ops.softmax_cross_entropy(o.reshape(-1, o.shape[-1]), t.reshape(-1), 500))
+            shape, classes = None, 500
         else:
             from ..models import resnet
             from .. import ops
@@ -124,7 +139,7 @@ def pp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, sta
             bounds = partition_balanced(param_costs(layers), stages)
             stage_mod = build_stage_module(layers, bounds, stage, full)
             loss_fn, shape, classes = (lambda o, t: ops.softmax_cross_entropy(o, t, 16)), (3, 32, 32), 16
-        x, y = _data(shape, classes, batch * replicas)
+        x, y = _data(shape, classes, batch * replicas) if shape is not None else _tokens(batch * replicas)
         x, y = x[replica * batch:(replica + 1) * batch].to(device), y[replica * batch:(replica + 1) * batch].to(device)
         stage_mod = stage_mod.to(device)
         dp = DataParallel(stage_mod, dp_comm) if (replicas > 1 or share_gpu) else None

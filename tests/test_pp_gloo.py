@@ -17,13 +17,20 @@ def _reference(model_name, batch, n_micro, replica=0, replicas=1):
         layers = mnist.mnist_stages()
         loss_fn, shape, classes = mnist.nll_loss, (1, 28, 28), 10
         names = [["" + n for n, _ in l.named_parameters()] for l in layers]
+    elif model_name == "gpt2_tiny":
+        from distributedpytorch_amd.models import gpt2
+        from distributedpytorch_amd import ops
+        full = gpt2.gpt2_tiny().train()
+        layers = full.pipeline_layers()
+        loss_fn = (lambda o, t: ops.softmax_cross_entropy(o.reshape(-1, o.shape[-1]), t.reshape(-1), 500))
+        shape, classes = None, 500
     else:
         from distributedpytorch_amd.models import resnet
         from distributedpytorch_amd import ops
         full = resnet.tiny_resnet().train()
         layers = full.pipeline_layers()
         loss_fn, shape, classes = (lambda o, t: ops.softmax_cross_entropy(o, t, 16)), (3, 32, 32), 16
-    x, y = T._data(shape, classes, batch * replicas)
+    x, y = T._data(shape, classes, batch * replicas) if shape is not None else T._tokens(batch * replicas)
     x, y = x[replica * batch:(replica + 1) * batch], y[replica * batch:(replica + 1) * batch]
     sizes = split_microbatches(batch, n_micro)
     off, total = 0, 0.0
@@ -94,3 +101,22 @@ def test_dp_x_pp_hybrid_2x2(tmp_path):
         b = torch.load(tmp_path / f"grads_r1_s{s}.pt", weights_only=True)
         for k in a:
             assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-7)
+
+
+def test_gpt2_pipeline_keeps_the_embedding_and_the_lm_head_tied(tmp_path):
+    """GPT-2 split over 2 stages: the token embedding (stage 0) and the LM head (last stage) are ONE matrix.  Both
+    stages must end backward with the SUM of the two uses' gradients (= the unsplit model's gradient of wte), apply
+    the same update and so keep identical copies."""
+    url = f"tcp://127.0.0.1:{T.free_port()}"
+    launch.spawn(T.pp_worker, [2], 0, args=(url, "gpt2_tiny", str(tmp_path), 2, 1, 2, "1f1b", 4, 3))
+    layers, ref_loss = _reference("gpt2_tiny", 4, 2)
+    wte_grad = layers[0].wte.grad                                   # one Parameter: embedding + head gradients summed
+    g0 = torch.load(tmp_path / "grads_r0_s0.pt", weights_only=True)
+    g1 = torch.load(tmp_path / "grads_r0_s1.pt", weights_only=True)
+    k0 = [k for k in g0 if k.endswith("wte")]; k1 = [k for k in g1 if k.endswith("wte")]
+    assert len(k0) == 1 and len(k1) == 1
+    assert torch.allclose(g0[k0[0]], wte_grad, rtol=2e-4, atol=1e-6) and torch.equal(g0[k0[0]], g1[k1[0]])
+    final = torch.load(tmp_path / "final_r0_s1.pt", weights_only=True)
+    assert abs(final["losses"][0] - ref_loss) < 1e-4 * max(1.0, abs(ref_loss)) and final["losses"][-1] < final["losses"][0]
+    sd = torch.load(str(tmp_path / "ckpt_r0.pt") + ".model", weights_only=True)          # merged checkpoint: one wte
+    assert sum(1 for k in sd if k.endswith("wte")) == 1
