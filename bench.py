@@ -110,6 +110,8 @@ def main():
     torch.manual_seed(1234)
     unit = "images/sec"
     if args.pipeline and args.pipeline > 1:
+        if args.model == "gpt2":
+            unit = "tokens/sec"
         from distributedpytorch_amd.parallel.pp import run_pipeline_bench
         result = run_pipeline_bench(args, communicator, device)
     else:

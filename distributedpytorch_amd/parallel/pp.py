@@ -320,16 +320,27 @@ def run_pipeline_bench(args, world: _comm.Communicator, device: torch.device) ->
         raise SystemExit(f"world size {n} is not a multiple of --pipeline {S}")
     replicas = n // S
     pp_comm, dp_comm, replica, stage = _comm.build_grid(world, replicas, S)
-    name = args.model if args.model in ("resnet50", "resnet152", "tiny_resnet") else "resnet152"
-    model = resnet.tiny_resnet() if name == "tiny_resnet" else getattr(resnet, name)()
-    hw, classes = (64, 16) if name == "tiny_resnet" else (224, 1000)
-    batch = args.batch or 256
+    if args.model == "mnist":
+        raise SystemExit("bench.py --pipeline: resnet50 / resnet152 / tiny_resnet / gpt2 (the 2-stage MNIST split is examples/mp.py)")
+    name = args.model
+    tokens = name == "gpt2"
+    g = torch.Generator(device=device).manual_seed(1234 + replica)
+    if tokens:
+        from ..models import gpt2
+        model = gpt2.gpt2_small()
+        classes, seq = model.cfg.vocab_size, args.seq_len
+        batch = args.batch or 8
+        t = torch.randint(0, classes, (batch, seq + 1), generator=g, device=device)
+        x, y = t[:, :-1].contiguous(), t[:, 1:].contiguous()
+    else:
+        model = resnet.tiny_resnet() if name == "tiny_resnet" else getattr(resnet, name)()
+        hw, classes = (64, 16) if name == "tiny_resnet" else (224, 1000)
+        batch = args.batch or 256
+        x = torch.randn(batch, 3, hw, hw, generator=g, device=device)
+        y = torch.randint(0, classes, (batch,), generator=g, device=device)
     model = model.to(device).train()
     layers = model.pipeline_layers()
     mb = max(1, batch // args.micro_batches)
-    g = torch.Generator(device=device).manual_seed(1234 + replica)
-    x = torch.randn(batch, 3, hw, hw, generator=g, device=device)
-    y = torch.randint(0, classes, (batch,), generator=g, device=device)
     costs = measure_costs(layers, x[:mb]) if device.type == "cuda" else param_costs(layers)
     # every rank must agree on the split: use stage 0 / replica 0's measurement
     costs = world.broadcast_object(costs, src=0)
@@ -340,7 +351,7 @@ def run_pipeline_bench(args, world: _comm.Communicator, device: torch.device) ->
                       use_sink=not args.no_sink)
     opt = FusedSGD(dp.flat, lr=0.1, momentum=0.9, weight_decay=1e-4)
     opt.grad_scale = dp.grad_scale
-    loss_fn = (lambda out, t: ops.softmax_cross_entropy(out, t, classes))
+    loss_fn = (lambda out, t: ops.softmax_cross_entropy(out.reshape(-1, out.shape[-1]), t.reshape(-1), classes))
     eng = PipelineStage(stage_mod, pp_comm, loss_fn, n_micro=args.micro_batches, schedule=args.schedule, dp=dp)
 
     def step():
@@ -364,7 +375,8 @@ def run_pipeline_bench(args, world: _comm.Communicator, device: torch.device) ->
     lossv = float(loss.float().cpu()) if loss is not None else float("nan")
     # the loss lives on the last stage; make rank 0 report it
     lossv = world.all_reduce_scalar(lossv if eng.last and replica == 0 else 0.0, "sum")
-    return {"elapsed": elapsed, "items_per_rank_step": batch, "dp_world": replicas, "loss": lossv,
-            "config": {"model": name, "global_batch": batch * replicas, "image": f"3x{hw}x{hw}",
-                       "parallelism": f"pp{S}xdp{replicas}", "micro_batches": args.micro_batches,
-                       "schedule": args.schedule, "stage_bounds": bounds}}
+    shape = {"seq_len": seq} if tokens else {"image": f"3x{hw}x{hw}"}
+    return {"elapsed": elapsed, "items_per_rank_step": batch * (seq if tokens else 1), "dp_world": replicas, "loss": lossv,
+            "config": dict({"model": "gpt2-small-124M" if tokens else name, "global_batch": batch * replicas,
+                            "parallelism": f"pp{S}xdp{replicas}", "micro_batches": args.micro_batches,
+                            "schedule": args.schedule, "stage_bounds": bounds}, **shape)}
