@@ -12,6 +12,7 @@ children explicitly, so the *spawn* start method works (the reference relies on
 from __future__ import annotations
 
 import argparse
+import os
 from dataclasses import dataclass, field, asdict
 from typing import List, Optional, Sequence
 
@@ -117,6 +118,9 @@ def _common_flags(p: argparse.ArgumentParser) -> None:
     p.add_argument("--log-json", default=None, type=str, help="append JSON-lines metrics to this file")
     p.add_argument("--timeout", default=300.0, type=float, help="rendezvous / collective timeout in seconds")
     p.add_argument("--sync-debug", action="store_true", help="synchronise after every comm op and check grads")
+    p.add_argument("--ifname", default=None, type=str,
+                   help="network interface for inter-node traffic: exported as NCCL_SOCKET_IFNAME and GLOO_SOCKET_IFNAME "
+                        "(the reference's README asks for `export GLOO_SOCKET_IFNAME=eth0` by hand, multinode-MP/README.md:12-14)")
 
 
 def dp_parser() -> argparse.ArgumentParser:
@@ -177,6 +181,9 @@ def config_from_args(args: argparse.Namespace, mode: str) -> TrainConfig:
         cfg.schedule = args.schedule
         cfg.stages = args.stages
         cfg.dp_replicas = args.dp_replicas
+    if getattr(args, "ifname", None):        # before any process is spawned: the children inherit it
+        os.environ["NCCL_SOCKET_IFNAME"] = args.ifname
+        os.environ["GLOO_SOCKET_IFNAME"] = args.ifname
     return cfg
 
 
