@@ -63,6 +63,7 @@ class TrainConfig:
     bucket_mb: float = 32.0
     first_bucket_mb: float = 4.0
     shard_optimizer: bool = False  # ZeRO stage 1 (optim.ShardedSGD)
+    graph: bool = True             # DP, small CNN on a GPU: replay forward+backward from a hipGraph
     micro_batches: int = 1
     schedule: str = "1f1b"
     stages: int = 2
@@ -133,6 +134,7 @@ def dp_parser() -> argparse.ArgumentParser:
     p.add_argument("--bucket-mb", default=32.0, type=float)
     p.add_argument("--first-bucket-mb", default=4.0, type=float)
     p.add_argument("--shard-optimizer", action="store_true", help="optimizer state sharded over the ranks (ZeRO stage 1)")
+    p.add_argument("--no-graph", action="store_true", help="small CNN on a GPU: do not replay the step from a hipGraph")
     return p
 
 
@@ -176,6 +178,7 @@ def config_from_args(args: argparse.Namespace, mode: str) -> TrainConfig:
         cfg.bucket_mb = args.bucket_mb
         cfg.first_bucket_mb = args.first_bucket_mb
         cfg.shard_optimizer = args.shard_optimizer
+        cfg.graph = not args.no_graph
     else:
         cfg.micro_batches = args.micro_batches
         cfg.schedule = args.schedule

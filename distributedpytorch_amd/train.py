@@ -97,6 +97,19 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
         if cfg.steps_per_epoch:
             num_batches = min(num_batches, cfg.steps_per_epoch)
         last = None
+        graphed = None
+        use_graph = cfg.graph and device.type == "cuda" and cfg.model == "mnist_cnn" and hasattr(model, "_drop")
+        if use_graph:
+            # launch-bound regime (the reference's CNN: ~20 kernels of a few microseconds): forward + backward are
+            # captured once into a hipGraph and replayed; ragged batches keep the eager path.  Captured here, on a
+            # placeholder batch, BEFORE the loader's prefetch thread exists: a capture must not race another
+            # thread's allocations and copies
+            from .parallel.graph import GraphedStep
+            x0, y0 = dataset.batch(list(range(min(int(bsz), len(dataset)))))
+            if x0.shape[0] == int(bsz):
+                model._drop.use_device_counter(device)
+                graphed = GraphedStep(dp, lambda a, b: loss_fn(model, a, b), (x0.to(device), y0.to(device)),
+                                      after_backward=model._drop.advance)
         guard = GCGuard(period=500)      # collector at a fixed step period, the same step on every rank (utils/gcguard.py)
         guard.__enter__()
         for epoch in range(start_epoch, cfg.epochs):
@@ -106,10 +119,15 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
             for step, (x, y) in enumerate(loader):
                 if cfg.steps_per_epoch and step >= cfg.steps_per_epoch:
                     break
-                loss = loss_fn(model, x, y)
-                epoch_loss += loss.detach()              # stays on device: no host sync (DP.py:153)
-                loss.backward()
-                dp.finish()                              # bucketed all-reduce, overlapped with backward
+                if graphed is not None and x.shape == graphed.static_inputs[0].shape:
+                    loss = graphed(x, y)
+                    epoch_loss += loss.detach()
+                    dp.reduce_all()                      # no hook fires in a replay: the engine launches the bucket(s)
+                else:
+                    loss = loss_fn(model, x, y)
+                    epoch_loss += loss.detach()          # stays on device: no host sync (DP.py:153)
+                    loss.backward()
+                    dp.finish()                          # bucketed all-reduce, overlapped with backward
                 if cfg.sync_debug and not cfg.shard_optimizer:   # (sharded: only the owner holds a shard's reduced gradient)
                     dmetrics.check_reduced_gradients(dp.flat, comm)
                 opt.step()                               # fused: scale, momentum, update, bf16 shadow, zero grad
