@@ -64,6 +64,12 @@ class TrainConfig:
     first_bucket_mb: float = 4.0
     shard_optimizer: bool = False  # ZeRO stage 1 (optim.ShardedSGD)
     graph: bool = True             # DP, small CNN on a GPU: replay forward+backward from a hipGraph
+    optimizer: str = "sgd"         # sgd | adamw
+    accum_steps: int = 1           # micro-steps accumulated locally per optimizer step
+    clip_grad_norm: float = 0.0    # global-norm clipping (0 = off)
+    warmup_steps: int = 0          # linear LR warm-up; with cosine_steps > 0 (or warm-up alone) a cosine decay follows
+    cosine_steps: int = 0
+    min_lr: float = 0.0
     micro_batches: int = 1
     schedule: str = "1f1b"
     stages: int = 2
@@ -135,6 +141,12 @@ def dp_parser() -> argparse.ArgumentParser:
     p.add_argument("--first-bucket-mb", default=4.0, type=float)
     p.add_argument("--shard-optimizer", action="store_true", help="optimizer state sharded over the ranks (ZeRO stage 1)")
     p.add_argument("--no-graph", action="store_true", help="small CNN on a GPU: do not replay the step from a hipGraph")
+    p.add_argument("--optimizer", default="sgd", choices=["sgd", "adamw"])
+    p.add_argument("--accum-steps", default=1, type=int, help="gradient accumulation: micro-steps per optimizer step")
+    p.add_argument("--clip-grad-norm", default=0.0, type=float, help="global gradient-norm clipping (0 = off)")
+    p.add_argument("--warmup-steps", default=0, type=int, help="linear LR warm-up steps (then cosine decay)")
+    p.add_argument("--cosine-steps", default=0, type=int, help="total steps of the cosine schedule (default: the whole run)")
+    p.add_argument("--min-lr", default=0.0, type=float)
     return p
 
 
@@ -179,6 +191,8 @@ def config_from_args(args: argparse.Namespace, mode: str) -> TrainConfig:
         cfg.first_bucket_mb = args.first_bucket_mb
         cfg.shard_optimizer = args.shard_optimizer
         cfg.graph = not args.no_graph
+        cfg.optimizer, cfg.accum_steps, cfg.clip_grad_norm = args.optimizer, args.accum_steps, args.clip_grad_norm
+        cfg.warmup_steps, cfg.cosine_steps, cfg.min_lr = args.warmup_steps, args.cosine_steps, args.min_lr
     else:
         cfg.micro_batches = args.micro_batches
         cfg.schedule = args.schedule

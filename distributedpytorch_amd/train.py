@@ -19,7 +19,7 @@ from . import data as ddata
 from . import metrics as dmetrics
 from .checkpoint import load_checkpoint, save_checkpoint
 from .config import TrainConfig
-from .optim import FusedSGD, ShardedSGD
+from .optim import FusedAdamW, FusedSGD, ShardedSGD, WarmupCosine, clip_grad_norm
 from .parallel.dp import DataParallel
 from .parallel.flat import FlatParams
 from .parallel.pp import PipelineStage, build_stage_module, partition_balanced, param_costs
@@ -82,7 +82,11 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                                               workers=max(1, cfg.workers))
         dp = DataParallel(model, comm, bucket_mb=cfg.bucket_mb, first_bucket_mb=cfg.first_bucket_mb,
                           use_lp=use_lp, shard_optimizer=cfg.shard_optimizer)   # ... and a broadcast from rank 0 for safety
-        if cfg.shard_optimizer:
+        if cfg.optimizer == "adamw":
+            if cfg.shard_optimizer:
+                raise ValueError("--shard-optimizer is implemented for SGD (optim.ShardedSGD)")
+            opt = FusedAdamW(dp.flat, lr=cfg.lr, weight_decay=cfg.weight_decay)
+        elif cfg.shard_optimizer:
             opt = ShardedSGD(dp, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
         else:
             opt = FusedSGD(dp.flat, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
@@ -110,6 +114,15 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                 model._drop.use_device_counter(device)
                 graphed = GraphedStep(dp, lambda a, b: loss_fn(model, a, b), (x0.to(device), y0.to(device)),
                                       after_backward=model._drop.advance)
+        accum = max(1, cfg.accum_steps)
+        if accum > 1:
+            graphed = None                                   # (the captured step has no accumulate-only variant)
+            opt.grad_scale = dp.grad_scale / accum           # mean over ranks AND over the accumulated micro-steps
+        steps_this_epoch = min(len(loader), cfg.steps_per_epoch) if cfg.steps_per_epoch else len(loader)
+        sched = None
+        if cfg.warmup_steps > 0 or cfg.cosine_steps > 0:
+            total_steps = cfg.cosine_steps or (cfg.epochs * -(-steps_this_epoch // accum))
+            sched = WarmupCosine(cfg.lr, cfg.warmup_steps, max(total_steps, cfg.warmup_steps + 1), cfg.min_lr)
         guard = GCGuard(period=500)      # collector at a fixed step period, the same step on every rank (utils/gcguard.py)
         guard.__enter__()
         for epoch in range(start_epoch, cfg.epochs):
@@ -123,6 +136,15 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                     loss = graphed(x, y)
                     epoch_loss += loss.detach()
                     dp.reduce_all()                      # no hook fires in a replay: the engine launches the bucket(s)
+                elif accum > 1 and (step + 1) % accum != 0 and step + 1 < steps_this_epoch:
+                    # gradient accumulation: local backward only, nothing on the wire until the last micro-step
+                    with dp.no_sync():
+                        loss = loss_fn(model, x, y)
+                        epoch_loss += loss.detach()
+                        loss.backward()
+                    meter.update(x.shape[0])
+                    guard.step()
+                    continue
                 else:
                     loss = loss_fn(model, x, y)
                     epoch_loss += loss.detach()          # stays on device: no host sync (DP.py:153)
@@ -130,6 +152,11 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                     dp.finish()                          # bucketed all-reduce, overlapped with backward
                 if cfg.sync_debug and not cfg.shard_optimizer:   # (sharded: only the owner holds a shard's reduced gradient)
                     dmetrics.check_reduced_gradients(dp.flat, comm)
+                if cfg.clip_grad_norm > 0:
+                    shard = (opt.lo, opt.hi) if cfg.shard_optimizer else None
+                    clip_grad_norm(dp.flat, cfg.clip_grad_norm, opt.grad_scale, shard, comm)
+                if sched is not None:
+                    sched.apply(opt, opt.steps)
                 opt.step()                               # fused: scale, momentum, update, bf16 shadow, zero grad
                 meter.update(x.shape[0])
                 guard.step()

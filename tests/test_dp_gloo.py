@@ -82,3 +82,22 @@ def test_sharded_optimizer_matches_the_replicated_one(tmp_path, model_name, worl
     for i, st in ref["opt"]["state"].items():
         assert torch.allclose(z[0]["opt"]["state"][i]["momentum_buffer"], st["momentum_buffer"], rtol=1e-5, atol=1e-7)
     assert z[0]["losses"][-1] < z[0]["losses"][0]
+
+
+@pytest.mark.parametrize("extra", [["--accum-steps=2", "--clip-grad-norm=1.0", "--warmup-steps=3"],
+                                   ["--optimizer=adamw", "--lr=0.002", "--accum-steps=3", "--clip-grad-norm=0.5"],
+                                   ["--shard-optimizer", "--clip-grad-norm=1.0", "--cosine-steps=16", "--min-lr=0.001"]])
+def test_training_loop_options_world2(tmp_path, capfd, extra):
+    """Gradient accumulation (no traffic on the accumulate-only micro-steps), global-norm clipping (shard-aware),
+    warm-up / cosine LR, AdamW and the sharded optimizer through the example CLI on gloo, world 2: the loop runs, the
+    loss goes down, and an accumulating run issues 1/accum of the all-reduces."""
+    import json
+    import re
+    from distributedpytorch_amd.examples import dp
+    log = tmp_path / "log.jsonl"
+    dp.main([f"--dist-url=tcp://127.0.0.1:{T.free_port()}", "--backend=gloo", "--node-index=0", "--GPU-list=2", "--epochs=3",
+             "--dataset-size=1024", "--steps-per-epoch=8", "--lr=0.05", "--momentum=0.9", f"--log-json={log}"] + extra)
+    out = capfd.readouterr().out
+    losses = [float(v) for v in re.findall(r"Rank  0  , epoch  \d+  :  ([0-9.]+)", out)]
+    assert len(losses) == 3 and losses[-1] < losses[0], losses
+    assert all(json.loads(l)["kind"] == "dp_epoch" for l in open(log))
