@@ -124,9 +124,10 @@ class ShardedSGD(FusedSGD):
             raise ValueError("ShardedSGD needs DataParallel(..., shard_optimizer=True)")
         self.dp, self.comm = dp, dp.comm
         self.lo, self.hi = dp.shards[dp.comm.rank], dp.shards[dp.comm.rank + 1]
-        super().__init__(dp.flat, lr, momentum, weight_decay, nesterov, no_decay)
+        super().__init__(dp.flat, lr, 0.0, weight_decay, nesterov, no_decay)     # (0.0: no full-size momentum buffer)
+        self.momentum = momentum
         self.grad_scale = dp.grad_scale
-        if self.momentum_buf is not None:                      # the parent allocated a full-size buffer: keep 1/N of it
+        if momentum != 0.0:                                    # 1/N of the replicated optimizer's state
             self.momentum_buf = torch.zeros(self.hi - self.lo, dtype=torch.float32, device=self.flat.device)
         # the weight-decay runs clipped to this shard, relative to its start
         self.shard_segments = [(max(a, self.lo) - self.lo, min(b, self.hi) - self.lo, w)
