@@ -54,6 +54,7 @@ class TrainConfig:
     weight_decay: float = 0.0
     seed: int = 1234
     workers: int = 0
+    device_data: bool = False      # synthetic image batches generated on the GPU instead of on the host
     # ---- model / data ----
     model: str = "mnist_cnn"
     dataset: str = "synthetic"
@@ -125,6 +126,8 @@ def _common_flags(p: argparse.ArgumentParser) -> None:
     p.add_argument("--log-json", default=None, type=str, help="append JSON-lines metrics to this file")
     p.add_argument("--timeout", default=300.0, type=float, help="rendezvous / collective timeout in seconds")
     p.add_argument("--sync-debug", action="store_true", help="synchronise after every comm op and check grads")
+    p.add_argument("--device-data", action="store_true",
+                   help="generate the synthetic image batches on the GPU (no host work, no H2D copy)")
     p.add_argument("--ifname", default=None, type=str,
                    help="network interface for inter-node traffic: exported as NCCL_SOCKET_IFNAME and GLOO_SOCKET_IFNAME "
                         "(the reference's README asks for `export GLOO_SOCKET_IFNAME=eth0` by hand, multinode-MP/README.md:12-14)")
@@ -184,7 +187,7 @@ def config_from_args(args: argparse.Namespace, mode: str) -> TrainConfig:
         model=args.model or defaults["model"], dataset_size=args.dataset_size,
         steps_per_epoch=args.steps_per_epoch, dtype=args.dtype, device=args.device,
         checkpoint=args.checkpoint, resume=args.resume, log_json=args.log_json,
-        timeout_s=args.timeout, sync_debug=args.sync_debug,
+        timeout_s=args.timeout, sync_debug=args.sync_debug, device_data=args.device_data,
     )
     if mode == "dp":
         cfg.bucket_mb = args.bucket_mb

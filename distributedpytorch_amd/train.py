@@ -55,13 +55,14 @@ def build_model(name: str):
     raise ValueError(f"unknown model {name!r}")
 
 
-def build_dataset(kind: str, cfg: TrainConfig, classes: int, model=None):
+def build_dataset(kind: str, cfg: TrainConfig, classes: int, model=None, device=None):
+    gen = dict(device=device, on_device=device is not None and device.type == "cuda" and cfg.device_data)
     if kind == "mnist":
-        return ddata.SyntheticImageDataset(cfg.dataset_size, (1, 28, 28), 10, cfg.seed)
+        return ddata.SyntheticImageDataset(cfg.dataset_size, (1, 28, 28), 10, cfg.seed, **gen)
     if kind == "imagenet":
-        return ddata.SyntheticImageDataset(cfg.dataset_size, (3, 224, 224), classes, cfg.seed)
+        return ddata.SyntheticImageDataset(cfg.dataset_size, (3, 224, 224), classes, cfg.seed, **gen)
     if kind == "tiny_image":
-        return ddata.SyntheticImageDataset(cfg.dataset_size, (3, 64, 64), classes, cfg.seed)
+        return ddata.SyntheticImageDataset(cfg.dataset_size, (3, 64, 64), classes, cfg.seed, **gen)
     if kind == "tokens":
         c = model.cfg
         return ddata.SyntheticTokenDataset(cfg.dataset_size, min(c.n_positions, 1024), c.vocab_size, cfg.seed)
@@ -77,7 +78,7 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
         torch.manual_seed(cfg.seed)                      # identical initial replicas (DP.py:138) ...
         model, kind, loss_fn, use_lp, classes = build_model(cfg.model)
         model = model.to(device).train()
-        dataset = build_dataset(kind, cfg, classes, model)
+        dataset = build_dataset(kind, cfg, classes, model, device)
         loader, bsz = ddata.partition_dataset(dataset, comm.rank, comm.world_size, cfg.batch_size, cfg.seed, device,
                                               workers=max(1, cfg.workers))
         dp = DataParallel(model, comm, bucket_mb=cfg.bucket_mb, first_bucket_mb=cfg.first_bucket_mb,
@@ -208,7 +209,7 @@ def run_mp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
             stage_mod = build_stage_module(layers, bounds, stage, full)
             loss_fn = (lambda out, t: ops.softmax_cross_entropy(out.reshape(-1, out.shape[-1]), t.reshape(-1), classes))
         stage_mod = stage_mod.to(device).train()
-        dataset = build_dataset(kind, cfg, classes, full)
+        dataset = build_dataset(kind, cfg, classes, full, device)
         # every rank walks the SAME un-shuffled loader (MP.py:104-116): stage 0 consumes the data, the
         # last stage the targets; replicas take disjoint shards
         if replicas > 1:
