@@ -62,6 +62,27 @@ def run(fn: Callable[[], None], keep: Sequence[torch.Tensor]) -> "torch.cuda.Eve
     return done
 
 
+class on_side_stream:
+    """Context: the side stream, first made to wait (on the device) for everything enqueued on the current stream."""
+
+    def __init__(self, device):
+        self.index = torch.device(device).index if not isinstance(device, int) else device
+        if self.index is None:
+            self.index = torch.cuda.current_device()
+        self.ctx = None
+
+    def __enter__(self):
+        side = _stream(self.index)
+        side.wait_stream(torch.cuda.current_stream(self.index))
+        _dirty[self.index] = True
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return side
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
 def wait(done: "torch.cuda.Event", produced: Sequence[torch.Tensor] = ()) -> None:
     """Order the current stream behind one side launch.  ``produced`` are tensors that launch ALLOCATED (they
     belong to the side stream's allocator pool): they are marked as used by the current stream so that their

@@ -21,6 +21,7 @@ backward:
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -30,6 +31,8 @@ from .. import comm as _comm
 from ..ops import side as _side
 from ..ops import sink as _sink
 from .flat import Bucket, FlatParams
+
+_AR_FROM_SIDE = os.environ.get("DPA_AR_FROM_SIDE", "1") != "0"
 
 
 def shard_bounds(total: int, world_size: int, align: int = 64) -> List[int]:
@@ -154,8 +157,18 @@ class DataParallel:
 
     def _launch(self, b: Bucket) -> None:
         view = self.flat.grad[b.start:b.end]
+        if view.is_cuda and _AR_FROM_SIDE and _side.active(view):
+            # The bucket's last gradients come from the side stream (ops/side.py).  Issued from THAT stream (which
+            # first waits for the compute stream, a device-side wait), the collective is ordered behind both streams
+            # and the compute stream itself never stalls on outstanding weight-gradient kernels.
+            with _side.on_side_stream(view.device):
+                self._issue(b, view)
+            return
         if view.is_cuda:
             _side.join(view.device)       # weight gradients are produced on the side stream (ops/side.py)
+        self._issue(b, view)
+
+    def _issue(self, b: Bucket, view: torch.Tensor) -> None:
         if self.shards is not None and self.world_size > 1:
             works = []
             for r in range(self.world_size):            # every rank walks the owners in the same order
