@@ -19,6 +19,7 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -64,7 +65,9 @@ class RcclComm {
         HIP_CHECK(hipSetDevice(device));
         int lo = 0, hi = 0;
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));     // hi = numerically lowest = highest priority
-        HIP_CHECK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi));
+        const char* pr = std::getenv("DPA_COMM_PRIO");          // "high" (default) | "normal"
+        const bool normal = pr != nullptr && std::string(pr) == "normal";
+        HIP_CHECK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, normal ? lo : hi));
         RCCL_CHECK(ncclCommInitRank(&comm_, world, id, rank));
     }
 
@@ -74,7 +77,6 @@ class RcclComm {
             (void)ncclCommDestroy(comm_);
         }
         for (auto& kv : pending_) (void)hipEventDestroy(kv.second.done);
-        for (hipEvent_t e : pool_) (void)hipEventDestroy(e);
         if (stream_ != nullptr) (void)hipStreamDestroy(stream_);
     }
 
@@ -174,13 +176,13 @@ class RcclComm {
         c10::hip::HIPGuardMasqueradingAsCUDA guard(c10::Device(c10::DeviceType::CUDA, (c10::DeviceIndex)device_));
         hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
         HIP_CHECK(hipStreamWaitEvent(cur, it->second.done, 0));
-        pool_.push_back(it->second.done);
+        HIP_CHECK(hipEventDestroy(it->second.done));
         pending_.erase(it);
     }
 
     void synchronize() {
         HIP_CHECK(hipStreamSynchronize(stream_));
-        for (auto& kv : pending_) pool_.push_back(kv.second.done);
+        for (auto& kv : pending_) HIP_CHECK(hipEventDestroy(kv.second.done));
         pending_.clear();
     }
 
@@ -193,8 +195,12 @@ class RcclComm {
     }
     static ncclRedOp_t red_op(int op) { return op == 1 ? ncclMax : op == 2 ? ncclMin : ncclSum; }
 
-    hipEvent_t get_event() {
-        if (!pool_.empty()) { hipEvent_t e = pool_.back(); pool_.pop_back(); return e; }
+    // Events are never re-recorded: a stream-wait on ROCm 7 followed the event's LATEST record when it finally executed,
+    // not the record that was current when the wait was enqueued, so re-recording a pooled event under a queued wait
+    // tied that wait to work submitted later - with bucket-sized (32 MB) operands the queues deadlocked.  Each use gets
+    // a fresh event, destroyed right after its wait is enqueued (destruction of an event in use is deferred by the
+    // runtime); creation costs about a microsecond, ten times per step.
+    static hipEvent_t new_event() {
         hipEvent_t e;
         HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         return e;
@@ -204,34 +210,25 @@ class RcclComm {
     void begin() {
         c10::hip::HIPGuardMasqueradingAsCUDA guard(c10::Device(c10::DeviceType::CUDA, (c10::DeviceIndex)device_));
         hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
-        hipEvent_t ready = get_event();
+        hipEvent_t ready = new_event();
         HIP_CHECK(hipEventRecord(ready, cur));
         HIP_CHECK(hipStreamWaitEvent(stream_, ready, 0));
-        pool_.push_back(ready);                              // a recorded event may be re-recorded once waited on; see get_event order
+        HIP_CHECK(hipEventDestroy(ready));
     }
 
     int64_t finish(std::vector<Tensor> keep) {
-        hipEvent_t done = get_fresh_event();
+        hipEvent_t done = new_event();
         HIP_CHECK(hipEventRecord(done, stream_));
         const int64_t ticket = next_ticket_++;
         pending_[ticket] = Pending{done, std::move(keep)};
         return ticket;
     }
 
-    // `begin` parks its event at the BACK of the pool; take completion events from the FRONT so that an
-    // event whose stream-wait was just enqueued is not re-recorded before older ones.
-    hipEvent_t get_fresh_event() {
-        if (pool_.size() > 8) { hipEvent_t e = pool_.front(); pool_.pop_front(); return e; }
-        hipEvent_t e;
-        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        return e;
-    }
 
     int rank_, world_, device_;
     ncclComm_t comm_ = nullptr;
     hipStream_t stream_ = nullptr;
     std::map<int64_t, Pending> pending_;
-    std::deque<hipEvent_t> pool_;
     int64_t next_ticket_ = 1;
 };
 
