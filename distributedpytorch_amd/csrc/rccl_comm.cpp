@@ -77,6 +77,7 @@ class RcclComm {
             (void)ncclCommDestroy(comm_);
         }
         for (auto& kv : pending_) (void)hipEventDestroy(kv.second.done);
+        for (hipEvent_t e : retired_) (void)hipEventDestroy(e);
         if (stream_ != nullptr) (void)hipStreamDestroy(stream_);
     }
 
@@ -176,7 +177,7 @@ class RcclComm {
         c10::hip::HIPGuardMasqueradingAsCUDA guard(c10::Device(c10::DeviceType::CUDA, (c10::DeviceIndex)device_));
         hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
         HIP_CHECK(hipStreamWaitEvent(cur, it->second.done, 0));
-        HIP_CHECK(hipEventDestroy(it->second.done));
+        retire(it->second.done);
         pending_.erase(it);
     }
 
@@ -200,6 +201,22 @@ class RcclComm {
     // tied that wait to work submitted later - with bucket-sized (32 MB) operands the queues deadlocked.  Each use gets
     // a fresh event, destroyed right after its wait is enqueued (destruction of an event in use is deferred by the
     // runtime); creation costs about a microsecond, ten times per step.
+    // A retired event still has a wait queued on some stream.  It is destroyed only after BOTH streams have drained:
+    // every kRetireBatch events (about 200 ResNet-50 steps) the communicator synchronises its stream and the current
+    // compute stream once - a few milliseconds every few seconds - and frees the batch.
+    static constexpr size_t kRetireBatch = 2048;
+    void retire(hipEvent_t e) {
+        retired_.push_back(e);
+        if (retired_.size() >= kRetireBatch) collect();
+    }
+    void collect() {
+        hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        HIP_CHECK(hipStreamSynchronize(cur));
+        for (hipEvent_t e : retired_) (void)hipEventDestroy(e);
+        retired_.clear();
+    }
+
     static hipEvent_t new_event() {
         hipEvent_t e;
         HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -213,7 +230,7 @@ class RcclComm {
         hipEvent_t ready = new_event();
         HIP_CHECK(hipEventRecord(ready, cur));
         HIP_CHECK(hipStreamWaitEvent(stream_, ready, 0));
-        HIP_CHECK(hipEventDestroy(ready));
+        retire(ready);
     }
 
     int64_t finish(std::vector<Tensor> keep) {
@@ -229,6 +246,7 @@ class RcclComm {
     ncclComm_t comm_ = nullptr;
     hipStream_t stream_ = nullptr;
     std::map<int64_t, Pending> pending_;
+    std::vector<hipEvent_t> retired_;
     int64_t next_ticket_ = 1;
 };
 
