@@ -841,6 +841,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         dpa::reduce_shards(dst.data_ptr<float>(), src.data_ptr<float>(), (int)nsrc, stride, dst.numel(), cur_stream());
     });
     m.def("mul_f32", &mul_f32);
+    m.def("reduce_shards_bf16", [](Tensor& dst, const Tensor& src, int64_t nsrc, int64_t stride, Tensor& out) {
+        CHECK_F32(dst); CHECK_BF16(src); CHECK_BF16(out);
+        TORCH_CHECK(nsrc >= 0 && src.numel() >= (nsrc > 0 ? (nsrc - 1) * stride + dst.numel() : 0) && out.numel() >= dst.numel(),
+                    "reduce_shards_bf16: buffers too small");
+        Guard g(dst);
+        dpa::reduce_shards_bf16(dst.data_ptr<float>(), src.data_ptr(), (int)nsrc, stride, dst.numel(), out.data_ptr(), cur_stream());
+    });
+    m.def("set_wide_gemm_min_tiles", [](int64_t n) { dpa::set_wide_gemm_min_tiles((int)n); });
+    m.def("wide_gemm_min_tiles", []() { return (int64_t)dpa::wide_gemm_min_tiles(); });
     bind_transformer(m);
     bind_rccl(m);
 }

@@ -398,6 +398,23 @@ void reduce_shards(float* dst, const float* src, int nsrc, long stride, long n, 
     hipLaunchKernelGGL(reduce_shards_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, dst, src, nsrc, stride, n);
 }
 
+// bf16 wire format of the direct all-reduce: dst[i] (fp32, this rank's own values) += sum_k bf16 src[k * stride + i], summed
+// in fp32; the result is written back in fp32 (dst) and in bf16 (out: what goes back on the wire)
+__global__ __launch_bounds__(256) void reduce_shards_bf16_kernel(float* __restrict__ dst, const unsigned short* __restrict__ src,
+                                                                 int nsrc, long stride, long n, unsigned short* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float a = dst[i];
+        for (int k = 0; k < nsrc; ++k) a += bf16_to_float(src[(long)k * stride + i]);
+        dst[i] = a;
+        out[i] = float_to_bf16(a);
+    }
+}
+
+void reduce_shards_bf16(float* dst, const void* src, int nsrc, long stride, long n, void* out, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_shards_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, st, dst, (const unsigned short*)src, nsrc,
+                       stride, n, (unsigned short*)out);
+}
+
 __global__ void counter_add_kernel(int64_t* c, int64_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += v; }
 
 void counter_add(int64_t* c, int64_t v, hipStream_t st) { hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, st, c, v); }

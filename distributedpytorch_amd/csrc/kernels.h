@@ -47,6 +47,13 @@ struct ConvArgs {
 };
 void conv_igemm(const ConvArgs& a, hipStream_t st);
 int conv_stats_rows(long M);  // replica rows of the stats buffer
+// 256 x 256-tile GEMM main loop (gemm_wide.hip) for the plain-GEMM launches (1x1, stride 1) whose grid fills the chip
+// with such tiles; conv_igemm() routes to it when wide_gemm_eligible().  set_wide_gemm_min_tiles(0) turns it off.
+bool wide_gemm_supported(const ConvArgs& a);
+bool wide_gemm_eligible(const ConvArgs& a);
+void gemm_wide(const ConvArgs& a, hipStream_t st);
+void set_wide_gemm_min_tiles(int n);
+int wide_gemm_min_tiles();
 
 // wgrad: dw[k,r,s,c] += sum_{n,ho,wo} dy[n,ho,wo,k] * x[n, ho*stride-pad+r, wo*stride-pad+s, c]
 // dw is fp32 and is accumulated into with float atomics (split over the pixel axis).
@@ -182,5 +189,7 @@ void counter_add(int64_t* c, int64_t v, hipStream_t st);
 // dst[i] += sum_{k<nsrc} src[k*stride + i], i < n (fp32; local step of the direct all-reduce)
 void reduce_shards(float* dst, const float* src, int nsrc, long stride, long n, hipStream_t st);   // device-resident step counter (graph-replay safe)
 void mul_f32(const float* a, const float* b, float* y, long n, hipStream_t st);
+// dst[i] += sum_{k<nsrc} bf16 src[k*stride + i] in fp32; out[i] = bf16(dst[i])  (bf16 wire format of the direct all-reduce)
+void reduce_shards_bf16(float* dst, const void* src, int nsrc, long stride, long n, void* out, hipStream_t st);
 
 }  // namespace dpa

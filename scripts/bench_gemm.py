@@ -1,6 +1,12 @@
 #!/usr/bin/env python
-"""GEMM shapes of GPT-2 small (tokens = 8192) through the conv kernels as R=S=1 convolutions: TFLOP/s."""
+"""GEMM shapes of GPT-2 small (tokens = 8192) and the large 1x1 layers of ResNet-50 through the conv kernels as
+R=S=1 convolutions: the 256 x 256 main loop (csrc/gemm_wide.hip) against the 128 x 128 one (csrc/conv_igemm.hip)
+and, with WITH_LIB=1, against the library GEMM (hipBLASLt through torch.matmul) - comparison line only, nothing in
+the framework calls it.  All arms run interleaved in ONE process on the same random operands (several rounds,
+median), since separate processes differ by more than the kernels do."""
+import json
 import os
+import statistics
 import sys
 
 import torch
@@ -11,21 +17,45 @@ from bench_conv import timeit  # noqa: E402
 
 C = _ext.load()
 M = int(os.environ.get("TOKENS", "8192"))
-for name, K_in, N_out in [("qkv 768->2304", 768, 2304), ("proj 768->768", 768, 768), ("fc 768->3072", 768, 3072),
-                          ("fc2 3072->768", 3072, 768), ("lm_head 768->50304", 768, 50304)]:
-    x = torch.randn(M, 1, 1, K_in, device="cuda").to(torch.bfloat16)
+ROUNDS = int(os.environ.get("ROUNDS", "5"))
+WITH_LIB = os.environ.get("WITH_LIB", "0") == "1"
+SHAPES = [("qkv 768->2304", M, 768, 2304), ("proj 768->768", M, 768, 768), ("fc 768->3072", M, 768, 3072),
+          ("fc2 3072->768", M, 3072, 768), ("lm_head 768->50304", M, 768, 50304),
+          ("r50 l3.c3 256->1024", 50176, 256, 1024), ("r50 l3.c1 1024->256", 50176, 1024, 256),
+          ("r50 l2.c3 128->512", 200704, 128, 512), ("r50 l4.c3 512->2048", 12544, 512, 2048)]
+only = os.environ.get("ONLY")
+rows = []
+for name, m, K_in, N_out in SHAPES:
+    if only and only not in name:
+        continue
+    x = torch.randn(m, 1, 1, K_in, device="cuda").to(torch.bfloat16)
     w = (torch.randn(N_out, 1, 1, K_in, device="cuda") * 0.02).to(torch.bfloat16)
-    dy = torch.randn(M, 1, 1, N_out, device="cuda").to(torch.bfloat16)
+    dy = torch.randn(m, 1, 1, N_out, device="cuda").to(torch.bfloat16)
     wt = C.transpose_filter(w)
-    dw = torch.zeros(N_out, 1, 1, K_in, device="cuda")
-    fl = 2.0 * M * K_in * N_out
-    tf = timeit(lambda: C.conv_fprop(x, w, None, 1, 0, 0, False, None), 10)
-    td = timeit(lambda: C.conv_dgrad(dy, wt, 1, 1, 1, 0, None, None), 10)
-    tw = timeit(lambda: C.conv_wgrad(x, dy, dw, 1, 0), 10)
-    if os.environ.get("WITH_LIB", "0") == "1":      # the library GEMM (hipBLASLt through torch) on the same operands
-        x2, w2, dy2 = x.view(M, K_in), w.view(N_out, K_in), dy.view(M, N_out)
-        lf = timeit(lambda: torch.matmul(x2, w2.t()), 10)
-        ld = timeit(lambda: torch.matmul(dy2, w2), 10)
-        lw = timeit(lambda: torch.matmul(dy2.t(), x2), 10)
-        print(f"{'  library':20s} fprop {lf:7.1f} us {fl / lf / 1e6:6.0f} TF | dgrad {ld:7.1f} us {fl / ld / 1e6:6.0f} TF | wgrad {lw:7.1f} us {fl / lw / 1e6:6.0f} TF", flush=True)
-    print(f"{name:20s} fprop {tf:7.1f} us {fl / tf / 1e6:6.0f} TF | dgrad {td:7.1f} us {fl / td / 1e6:6.0f} TF | wgrad {tw:7.1f} us {fl / tw / 1e6:6.0f} TF", flush=True)
+    fl = 2.0 * m * K_in * N_out
+    arms = {"wide fprop": (1, lambda: C.conv_fprop(x, w, None, 1, 0, 0, False, None)),
+            "128  fprop": (0, lambda: C.conv_fprop(x, w, None, 1, 0, 0, False, None)),
+            "wide dgrad": (1, lambda: C.conv_dgrad(dy, wt, 1, 1, 1, 0, None, None)),
+            "128  dgrad": (0, lambda: C.conv_dgrad(dy, wt, 1, 1, 1, 0, None, None))}
+    if WITH_LIB:
+        x2, w2, dy2 = x.view(m, K_in), w.view(N_out, K_in), dy.view(m, N_out)
+        arms["lib  fprop"] = (0, lambda: torch.matmul(x2, w2.t()))
+        arms["lib  dgrad"] = (0, lambda: torch.matmul(dy2, w2))
+    times = {k: [] for k in arms}
+    for _ in range(ROUNDS):
+        for k, (mt, fn) in arms.items():
+            C.set_wide_gemm_min_tiles(mt)
+            times[k].append(timeit(fn, 10))
+    C.set_wide_gemm_min_tiles(1)
+    row = {"name": name, "M": m, "K": K_in, "N": N_out}
+    line = f"{name:22s}"
+    for k in arms:
+        med, best = statistics.median(times[k]), min(times[k])
+        row[k] = {"median_us": med, "min_us": best, "tflops_median": fl / med / 1e6}
+        line += f" | {k} {med:7.1f} us {fl / med / 1e6:5.0f} TF"
+    rows.append(row)
+    print(line, flush=True)
+out = os.environ.get("OUT")
+if out:
+    with open(out, "w") as f:
+        json.dump(rows, f, indent=1)

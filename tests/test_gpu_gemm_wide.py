@@ -1,0 +1,145 @@
+"""The 256 x 256-tile GEMM main loop (csrc/gemm_wide.hip) against an fp32 reference AND against the 128 x 128
+kernel it replaces on large grids (same operands, same epilogue: the two may differ by summation order only).
+
+Shapes are chosen to hit: one K tile (K = 64: prologue and tail only), two, an odd count; ragged pixel and channel
+edges (rows / columns past M / N must read zeros and never be written); more tiles than one group of 8 pixel
+tiles; every fused epilogue the kernel implements.  Operands are random and asymmetric.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _C():
+    from distributedpytorch_amd.ops import _ext
+    return _ext.load()
+
+
+def _rand(shape, scale, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(DEV)
+
+
+class _Wide:
+    """Route every eligible launch to the wide kernel (min tiles 1) or to the 128 x 128 kernel (0)."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        C = _C()
+        self.keep = C.wide_gemm_min_tiles()
+        C.set_wide_gemm_min_tiles(1 if self.on else 0)
+
+    def __exit__(self, *exc):
+        _C().set_wide_gemm_min_tiles(self.keep)
+        return False
+
+
+def _check(got, ref, narrow, what):
+    got, ref, narrow = got.float().cpu(), ref.float().cpu(), narrow.float().cpu()
+    scale = float(ref.abs().max())
+    err = (got - ref).abs()
+    assert float(err.max()) <= 2e-2 * scale + 1e-3, f"{what}: max err {float(err.max()):.4g} vs fp32 reference (scale {scale:.4g})"
+    # against the other kernel: one bf16 rounding of an fp32 sum taken in a different order
+    d = (got - narrow).abs()
+    tol = 8e-3 * narrow.abs() + 1e-4 * scale + 1e-6
+    bad = int((d > tol).sum())
+    assert bad == 0, f"{what}: {bad}/{d.numel()} elements differ from the 128x128 kernel beyond one rounding, max {float(d.max()):.4g}"
+
+
+SHAPES = [(256, 64, 256), (300, 128, 264), (1000, 768, 776), (513, 192, 520), (2304, 64, 512), (4096, 320, 256)]
+
+
+@pytest.mark.parametrize("M,K,N", SHAPES)
+def test_wide_gemm_forward_plain(M, K, N):
+    C = _C()
+    x = _rand((M, 1, 1, K), 1.0, 1)
+    w = _rand((N, 1, 1, K), 0.1, 2)
+    with _Wide(True):
+        y = C.conv_fprop(x, w, None, 1, 0, 0, False, None)[0]
+    with _Wide(False):
+        y0 = C.conv_fprop(x, w, None, 1, 0, 0, False, None)[0]
+    ref = x.float().view(M, K) @ w.float().view(N, K).t()
+    _check(y.view(M, N), ref, y0.view(M, N), f"fprop {M}x{N}x{K}")
+
+
+def test_wide_gemm_identity_weights_place_every_column_where_it_belongs():
+    """A = I-style check with an asymmetric operand: w = identity-like selector, so y[m][n] = x[m][perm[n]] exactly -
+    a transposed, shifted or swizzle-mismatched tile cannot pass."""
+    C = _C()
+    M, K, N = 520, 256, 512
+    x = _rand((M, 1, 1, K), 1.0, 3)
+    perm = torch.randperm(K, generator=torch.Generator().manual_seed(4))
+    sel = torch.zeros(N, K)
+    cols = torch.arange(N)
+    sel[cols, perm[cols % K]] = 1.0
+    w = sel.to(torch.bfloat16).to(DEV).view(N, 1, 1, K)
+    with _Wide(True):
+        y = C.conv_fprop(x, w, None, 1, 0, 0, False, None)[0].view(M, N)
+    want = x.view(M, K)[:, perm[cols % K].to(DEV)]
+    assert torch.equal(y, want)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_wide_gemm_bias_activation_residual_and_twin(act):
+    C = _C()
+    M, K, N = 700, 128, 520
+    x = _rand((M, 1, 1, K), 1.0, 5)
+    w = _rand((N, 1, 1, K), 0.1, 6)
+    bias = torch.randn(N, device=DEV) * 0.5
+    res = _rand((M, 1, 1, N), 1.0, 7)
+    outs = []
+    for on in (True, False):
+        with _Wide(on):
+            ya = C.conv_fprop(x, w, bias, 1, 0, act, False, None)[0]
+            if act == 0:
+                yr = C.conv_fprop(x, w, bias, 1, 0, 0, False, None, res)[0]
+                yt, tw = C.conv_fprop(x, w, bias, 1, 0, 0, False, None, None, True)
+            else:
+                yr = yt = tw = ya
+        outs.append((ya, yr, yt, tw))
+    lin = x.float().view(M, K) @ w.float().view(N, K).t() + bias
+    ref = lin if act == 0 else torch.relu(lin) if act == 1 else torch.nn.functional.gelu(lin, approximate="tanh")
+    (ya, yr, yt, tw), (ya0, yr0, yt0, tw0) = outs
+    _check(ya.view(M, N), ref, ya0.view(M, N), f"bias act {act}")
+    if act == 0:
+        _check(yr.view(M, N), lin + res.float().view(M, N), yr0.view(M, N), "residual epilogue")
+        assert torch.equal(yt, ya)
+        assert torch.equal(tw, C.ew2(ya, ya, 3)), "the activated twin is gelu of the stored bf16 values"
+
+
+@pytest.mark.parametrize("M,K,N", [(600, 256, 264), (1024, 64, 768), (333, 1024, 256)])
+def test_wide_gemm_input_gradient_with_addend_mask_and_gelu_backward(M, K, N):
+    """mode 1 (dgrad of a Linear / 1x1 conv): dy [M, K] x wt [N, K]; plain, + masked addend, x gelu'(h)."""
+    C = _C()
+    dy = _rand((M, 1, 1, K), 1.0, 8)
+    wt = _rand((N, 1, 1, K), 0.1, 9)
+    add = _rand((M, 1, 1, N), 1.0, 10)
+    mask = torch.randint(0, 256, (M * N // 8,), dtype=torch.uint8, generator=torch.Generator().manual_seed(11)).to(DEV)
+    h = _rand((M, 1, 1, N), 1.5, 12)
+    got = []
+    for on in (True, False):
+        with _Wide(on):
+            p = C.conv_dgrad(dy, wt, 1, 1, 1, 0, None, None)
+            a = C.conv_dgrad(dy, wt, 1, 1, 1, 0, add, None)
+            am = C.conv_dgrad(dy, wt, 1, 1, 1, 0, add, mask)
+            g = C.conv_dgrad(dy, wt, 1, 1, 1, 0, None, None, None, None, None, h)
+        got.append((p, a, am, g))
+    ref = dy.float().view(M, K) @ wt.float().view(N, K).t()
+    bits = ((mask.view(-1, 1).cpu() >> torch.arange(8).view(1, 8)) & 1).view(M, N).float().to(DEV)
+    hf = h.float().view(M, N).requires_grad_()
+    torch.nn.functional.gelu(hf, approximate="tanh").sum().backward()
+    wide, narrow = got
+    _check(wide[0].view(M, N), ref, narrow[0].view(M, N), "dgrad")
+    _check(wide[1].view(M, N), ref + add.float().view(M, N), narrow[1].view(M, N), "dgrad + addend")
+    _check(wide[2].view(M, N), ref + add.float().view(M, N) * bits, narrow[2].view(M, N), "dgrad + masked addend")
+    _check(wide[3].view(M, N), ref * hf.grad, narrow[3].view(M, N), "dgrad x gelu'")
+
+
+def test_wide_gemm_is_what_large_launches_use_by_default_and_small_ones_do_not():
+    C = _C()
+    assert C.wide_gemm_min_tiles() > 0, "the wide kernel must be on by default (DPA_WIDE_MIN_TILES=0 disables it)"
