@@ -112,6 +112,15 @@ __device__ __forceinline__ float gelu_tanh_grad_fast(float x) {
     return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * k0 * (1.f + 3.f * k1 * x2);
 }
 
+// tanh-approximated GELU with tanh from one v_exp_f32 + one v_rcp_f32 (GEMM epilogues)
+__device__ __forceinline__ float gelu_tanh_fast(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float u = k0 * (x + k1 * x * x * x);
+    const float e = __builtin_amdgcn_exp2f(fminf(u * 2.885390081777927f, 80.f));      // e^(2u), clamped (tanh -> 1)
+    const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+    return 0.5f * x * (1.f + t);
+}
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace dpa

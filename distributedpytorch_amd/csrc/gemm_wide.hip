@@ -1,42 +1,54 @@
-// Wide-tile bf16 GEMM for gfx950: 256 x 256 output tile, K step 64, 8 waves (512 threads), one
-// workgroup per CU with 128 KiB of LDS, operands by LDS-DMA (buffer_load ... lds) kept in flight
-// ACROSS barriers behind counted s_waitcnt vmcnt(N).
+// Wide-tile bf16 GEMM for gfx950: PERSISTENT workgroups, 256 x 256 output tile, K step 64, 8 waves (512
+// threads), one workgroup per CU with 128 KiB of LDS, operands by LDS-DMA (buffer_load ... lds) kept in flight
+// ACROSS barriers and ACROSS output tiles behind counted s_waitcnt vmcnt(N).
 //
 //     y[m][n] = sum_k x[m][k] * w[n][k]          (both operands K-contiguous, fp32 accumulation)
 //
-// This is the R = S = 1, stride 1 case of ConvArgs (kernels.h): every Linear layer (forward and
-// input gradient), every 1x1 convolution.  conv_igemm() routes a launch here when the grid fills
-// the chip with 256-wide tiles (wide_gemm_eligible below); the 128 x 128 kernel of conv_igemm.hip
-// keeps the rest.  Why a second main loop: the 128^2 / BK=32 loop stages 64 FLOP per byte through
-// L2 -> LDS and pays a barrier every 32-deep K step; it tops out near 0.7 PFLOP/s (docs/DESIGN.md
-// section 6).  This loop stages 128 FLOP per byte and never drains the load queue:
+// This is the R = S = 1, stride 1 case of ConvArgs (kernels.h): every Linear layer (forward and input
+// gradient), every 1x1 convolution.  conv_igemm() routes a launch here when the grid fills the chip with
+// 256-wide tiles (wide_gemm_eligible below); the 128 x 128 kernel of conv_igemm.hip keeps the rest.  Why a
+// second main loop: the 128^2 / BK=32 loop stages 64 FLOP per byte through L2 -> LDS and pays a barrier every
+// 32-deep K step; it tops out near 0.7 PFLOP/s (docs/DESIGN.md section 6).  This loop stages 128 FLOP per byte
+// and never drains the load queue:
 //
-//   * wave (wr, wc), wr = wave >> 2, wc = wave & 3, owns 128 output channels x 64 pixels as
-//     8 x 4 MFMA tiles (v_mfma_f32_16x16x32_bf16; A operand = filter rows, B operand = pixel rows,
-//     so a lane ends up with 4 consecutive channels of one pixel);
-//   * a K step is FOUR phases of 16 MFMAs (one quadrant of the wave tile each); a phase is a LOAD
-//     segment (the quadrant's fragment reads, two 1-KiB DMA pieces of a LATER K tile, a counted
-//     vmcnt) and an MFMA segment, each closed by a raw s_barrier;
-//   * waves 4-7 run ONE barrier behind waves 0-3, so on every SIMD one wave is in its MFMA segment
-//     while its partner is in its load segment (the two waves of a SIMD share the matrix pipe, so
-//     two MFMA segments side by side would gain nothing; matrix beside memory does);
-//   * each K tile is cut into four 16-KiB regions (filter rows of quadrants 0-1 / 2-3, pixel rows
-//     of quadrants 0,3 / 1,2), each read from LDS in exactly ONE phase (the fragments then live in
-//     registers), so a region of the buffer can be re-filled long before the whole tile is done:
-//     every DMA is issued 5-6 phases ahead of its first read and at least 2 phases after the last
-//     read of what it overwrites; `s_waitcnt vmcnt(8)` at the end of every load segment retires
-//     exactly the region the NEXT phase reads (8 = 2 pieces x the 4 regions issued since);
-//   * LDS rows are 128 B (64 bf16); the 16-byte chunk index is XOR-ed with (row & 7): the
-//     ds_read_b128 fragment reads are bank-conflict free.  The DMA's LDS image is lane-linear, so
-//     the swizzle is applied to the SOURCE address (lane -> chunk (lane & 7) ^ (lane >> 3));
-//   * XCD-aware, grouped tile order: a workgroup's id is first mapped so that the workgroups of one
-//     XCD (id mod 8) own a contiguous range of tiles, then tiles are walked 8 pixel tiles x
-//     4.. channel tiles at a time: the 32 workgroups running on an XCD share 8 + 4 operand panels
-//     in its 4 MiB L2 instead of 1 + 32.
-//   * epilogue: each wave stages its own 64 x 128 tile in a private LDS region (no workgroup
-//     barrier) and writes 256 contiguous bytes per pixel row, 16 B per lane; bias / activation /
-//     residual addend (+ bit mask) / GELU backward / activated twin are applied there.
+//   * wave (wr, wc), wr = wave >> 2, wc = wave & 3, owns 128 output channels x 64 pixels as 8 x 4 MFMA
+//     tiles (v_mfma_f32_16x16x32_bf16; A operand = filter rows, B operand = pixel rows, so a lane ends up
+//     with 4 consecutive channels of one pixel);
+//   * a K step is FOUR phases of 16 MFMAs (one quadrant of the wave tile each); a phase is a LOAD segment
+//     (the quadrant's fragment reads, two 1-KiB DMA pieces of a LATER K step, a counted vmcnt) and an MFMA
+//     segment, each closed by a raw s_barrier;
+//   * waves 4-7 run ONE barrier behind waves 0-3, so on every SIMD one wave is in its MFMA segment while
+//     its partner is in its load segment (the two waves of a SIMD share the matrix pipe, so two MFMA
+//     segments side by side would gain nothing; matrix beside memory does);
+//   * each K tile is cut into four 16-KiB regions (filter rows of quadrants 0-1 / 2-3, pixel rows of
+//     quadrants 0,3 / 1,2), each read from LDS in exactly ONE phase (the fragments then live in registers),
+//     so a region of the buffer can be re-filled long before the whole tile is done: every DMA is issued
+//     5-6 phases ahead of its first read and at least 2 phases after the last read of what it overwrites;
+//     `s_waitcnt vmcnt(8)` at the end of every load segment retires exactly the region the NEXT phase reads
+//     (8 = 2 pieces x the 4 regions issued since);
+//   * LDS rows are 128 B (64 bf16); the 16-byte chunk index is XOR-ed with (row & 7): the ds_read_b128
+//     fragment reads are bank-conflict free.  The DMA's LDS image is lane-linear, so the swizzle is applied
+//     to the SOURCE address (lane -> chunk (lane & 7) ^ (lane >> 3));
+//   * PERSISTENT: <= 256 workgroups each walk a list of work items (output tile, K range).  The four region
+//     cursors that feed the DMA run ahead of the MFMAs THROUGH item boundaries, so the next tile's first
+//     K steps are already in LDS when the current tile's last MFMA retires: no prologue latency per tile,
+//     and the epilogue's stores drain behind the next tile's main loop instead of in front of an idle CU
+//     (measured with one workgroup per tile: 11 us of fixed cost per 256 x 256 x 768 tile against 16 us of
+//     main loop, scripts/one_gemm.py).  vmcnt counts stores too, in issue order, so the four load segments
+//     that follow an epilogue allow its stores to stay outstanding (vmcnt(8 + stores)); every epilogue
+//     issues EXACTLY the same number of store instructions (range-checked buffer stores, no branches);
+//   * epilogue straight from registers: v_permlane16_swap pairs two adjacent channel tiles so that a lane
+//     holds 8 consecutive channels (16 B) of one pixel - no LDS staging (the LDS belongs to the DMA running
+//     ahead).  bias / activation / residual addend (+ bit mask) / GELU backward are applied there;
+//   * split K (deep K, few tiles: the LM head's input gradient is 96 tiles x 786 K steps): an item is a
+//     K range of a tile; partial tiles go to an fp32 workspace slab per split with plain 16-B stores and one
+//     small kernel folds the slabs in a fixed order (deterministic, no atomics) and applies the epilogue;
+//   * XCD-aware, grouped item order: the workgroups of one XCD (id mod 8) own a contiguous range of items,
+//     walked 8 pixel tiles x 4.. channel tiles at a time: the 32 workgroups running on an XCD share 8 + 4
+//     operand panels in its 4 MiB L2 instead of 1 + 32.
 #include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
 #include "common.h"
 #include "kernels.h"
 
@@ -48,12 +60,12 @@ constexpr int WBK = 64;                    // K step (bf16 elements)
 constexpr int ROWB = WBK * 2;              // bytes per LDS tile row
 constexpr int TILE_B = 256 * ROWB;         // one operand tile: 32 KiB
 constexpr int BUF_B = 2 * TILE_B;          // one K tile: filter rows, then pixel rows
-constexpr int EPI_ROWB = 128 * 2 + 16;     // staged output row of a wave: 128 channels + 16 B pad
-constexpr int EPI_WAVE_B = 64 * EPI_ROWB;  // 17,408 B per wave
-constexpr int WIDE_LDS = (2 * BUF_B > 8 * EPI_WAVE_B) ? 2 * BUF_B : 8 * EPI_WAVE_B;   // 139,264 B
-constexpr unsigned OOB = 0x80000000u;      // byte offset past every buffer (operands are < 2^31 bytes)
+constexpr int WIDE_LDS = 2 * BUF_B;        // 128 KiB
+constexpr unsigned OOB = 0x80000000u;      // byte offset past every operand (operands are < 2^31 bytes)
+constexpr int GM = 8;                      // pixel tiles per group of the item order
 
 typedef __attribute__((address_space(3))) unsigned char* lds_byte_ptr;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 // one 1-KiB LDS-DMA piece: 16 B per lane from buffer offset `voff` to LDS address `lds_addr` + 16 * lane
 __device__ __forceinline__ void dma_piece(u32x4 rs4, unsigned lds_addr, unsigned voff) {
@@ -61,62 +73,95 @@ __device__ __forceinline__ void dma_piece(u32x4 rs4, unsigned lds_addr, unsigned
                  :: "v"(voff), "s"(rs4), "s"(lds_addr) : "memory", "m0");
 }
 
-__global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, int tiles_m, int tiles_n, int M, int Kd) {
+struct WideArgs {
+    int tiles_m, tiles_n, M, Kd;
+    int splitk, nks;          // K steps per split (splitk == 1: nks = all)
+    int items;                // tiles_m * tiles_n * splitk
+    float* ws;                // splitk > 1: [splitk][M][N] fp32 partial sums
+    int dbg;                  // timing experiments: bit 0 = drop the output stores (zero-record descriptor)
+    int skew;                 // start-up skew: workgroup b sleeps b * skew / 256 periods of 8128 cycles before its first item
+};
+
+__global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int Nn = a.K;                                  // output channels = GEMM columns
+    const int M = g.M, Kd = g.Kd, nk = Kd / WBK;
 
-    // ---- tile of this workgroup: XCD-contiguous id, then groups of 8 pixel tiles ----
-    int lid;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        lid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
-    }
-    constexpr int GM = 8;
-    const int width = GM * tiles_n, grp = lid / width, first = grp * GM;
-    const int gsz = min(tiles_m - first, GM), inner = lid - grp * width;
-    const int tm = first + inner % gsz, tn = inner / gsz;
-    const int m0 = tm * 256, c0 = tn * 256;
+    // ---- this workgroup's items: the workgroups of one XCD own a contiguous range ----
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3, nb = (G - xcd + 7) >> 3;
+    const int iq = g.items >> 3, ir = g.items & 7;
+    const int istart = xcd < ir ? xcd * (iq + 1) : ir * (iq + 1) + (xcd - ir) * iq;
+    const int icount = iq + (xcd < ir ? 1 : 0);
+    const int nseq = slot < icount ? (icount - slot + nb - 1) / nb : 0;
+    if (nseq == 0) return;                               // workgroup-uniform
+    // Start-up skew.  Items of one launch are equally long, so workgroups that start together reach their epilogues
+    // together: 256 CUs x 128 KiB of stores every ~16 us arrive at HBM as one burst that takes ~5 us to drain, and vmcnt
+    // retires in order, so each wave then sits on its next loads until its own stores are through.  Started a fraction
+    // of an item apart, the CUs store at different times and the write stream to HBM is steady.
+    for (int i = (bid * g.skew) >> 8; i > 0; --i) __builtin_amdgcn_s_sleep(127);
+    auto item_coords = [&](int seq, int& tm, int& tn, int& z) {
+        const int L = istart + slot + seq * nb;
+        const int tile = L / g.splitk;
+        z = L - tile * g.splitk;
+        const int width = GM * g.tiles_n, grp = tile / width, first = grp * GM;
+        const int gsz = min(g.tiles_m - first, GM), inner = tile - grp * width;
+        tm = first + inner % gsz; tn = inner / gsz;
+    };
 
     const unsigned xbytes = (unsigned)M * (unsigned)Kd * 2u, wbytes = (unsigned)Nn * (unsigned)Kd * 2u;
     const u32x4 xrs4 = buffer_words(a.x, xbytes), wrs4 = buffer_words(a.w, wbytes);
     const unsigned lds0 = (unsigned)(unsigned long long)(lds_byte_ptr)wsm;
 
     // ---- DMA plan of this wave: per region two pieces of 8 rows x 128 B ----
-    // filter region X (0: channel tiles 0-3 of both wave rows, 1: tiles 4-7): 8-row group q = 2 * wave + u
-    //   covers rows (q >> 3) * 128 + X * 64 + (q & 7) * 8 ..;  pixel region Y (0: pixel tiles 0-1 of every
-    //   wave column, 1: tiles 2-3): rows (q >> 2) * 64 + Y * 32 + (q & 3) * 8 ..
+    // filter region R (0: channel tiles 0-3 of both wave rows, 1: tiles 4-7): 8-row group q = 2 * wave + u covers
+    //   rows (q >> 3) * 128 + R * 64 + (q & 7) * 8 ..;  pixel region R (0: pixel tiles 0-1 of every wave column,
+    //   1: tiles 2-3): rows (q >> 2) * 64 + R * 32 + (q & 3) * 8 ..
     const int lrow = lane >> 3;
     const unsigned src_chunk = (unsigned)((lane & 7) ^ lrow) * 16u;       // source-side swizzle (see header)
-    unsigned woff[2][2], xoff[2][2], wlds[2][2], xlds[2][2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int q = wave * 2 + u;
-            const int wrow = (q >> 3) * 128 + r * 64 + (q & 7) * 8;
-            const int xrow = (q >> 2) * 64 + r * 32 + (q & 3) * 8;
-            wlds[r][u] = lds0 + (unsigned)wrow * ROWB;
-            xlds[r][u] = lds0 + TILE_B + (unsigned)xrow * ROWB;
-            const int ch = c0 + wrow + lrow, px = m0 + xrow + lrow;
-            woff[r][u] = ch < Nn ? (unsigned)ch * (unsigned)Kd * 2u + src_chunk : OOB;
-            xoff[r][u] = px < M ? (unsigned)px * (unsigned)Kd * 2u + src_chunk : OOB;
-        }
-    const int nk = Kd / WBK;
-
-#define WG_DMA(RS4, OFF, LDS, REG, KT)                                                            \
+    // (formulas instead of arrays: an array indexed by a lambda parameter is demoted to scratch memory)
+#define WG_WROW(R, U) ((((wave * 2 + (U)) >> 3) * 128) + (R) * 64 + (((wave * 2 + (U)) & 7) * 8))
+#define WG_XROW(R, U) ((((wave * 2 + (U)) >> 2) * 64) + (R) * 32 + (((wave * 2 + (U)) & 3) * 8))
+#define WG_WLDS(R, U) (lds0 + (unsigned)WG_WROW(R, U) * ROWB)
+#define WG_XLDS(R, U) (lds0 + TILE_B + (unsigned)WG_XROW(R, U) * ROWB)
+    // place cursor P (half R of both operands) at the first K step of item SEQ (plain locals and a macro: a struct
+    // handed to a lambda by reference ended up in scratch memory)
+    unsigned c0_w0, c0_w1, c0_x0, c0_x1, c1_w0, c1_w1, c1_x0, c1_x1, c0_par = 0u, c1_par = 0u;
+    int c0_kt, c0_kend, c0_seq, c1_kt, c1_kend, c1_seq;
+#define WG_SEEK(P, R, SEQ)                                                                        \
     {                                                                                             \
-        const int kt_ = (KT);                                                                     \
-        const bool ok_ = kt_ < nk;                                                                \
-        const unsigned kb_ = (unsigned)kt_ * (unsigned)ROWB, bo_ = (unsigned)(kt_ & 1) * BUF_B;   \
-        _Pragma("unroll") for (int u = 0; u < 2; ++u)                                             \
-            dma_piece(RS4, LDS[REG][u] + bo_, ok_ ? OFF[REG][u] + kb_ : OOB);                     \
+        P##_seq = (SEQ);                                                                          \
+        if (P##_seq >= nseq) {                                                                    \
+            P##_w0 = P##_w1 = P##_x0 = P##_x1 = OOB; P##_kt = 0; P##_kend = 0x7fffffff;           \
+        } else {                                                                                  \
+            int tm_, tn_, z_;                                                                     \
+            item_coords(P##_seq, tm_, tn_, z_);                                                   \
+            P##_kt = z_ * g.nks;                                                                  \
+            P##_kend = min(nk, P##_kt + g.nks);                                                   \
+            const int w0_ = tn_ * 256 + WG_WROW(R, 0) + lrow, w1_ = tn_ * 256 + WG_WROW(R, 1) + lrow; \
+            P##_w0 = w0_ < Nn ? (unsigned)w0_ * (unsigned)Kd * 2u + src_chunk : OOB;              \
+            P##_w1 = w1_ < Nn ? (unsigned)w1_ * (unsigned)Kd * 2u + src_chunk : OOB;              \
+            const int x0_ = tm_ * 256 + WG_XROW(R, 0) + lrow, x1_ = tm_ * 256 + WG_XROW(R, 1) + lrow; \
+            P##_x0 = x0_ < M ? (unsigned)x0_ * (unsigned)Kd * 2u + src_chunk : OOB;               \
+            P##_x1 = x1_ < M ? (unsigned)x1_ * (unsigned)Kd * 2u + src_chunk : OOB;               \
+        }                                                                                         \
     }
-#define WG_DMA_W(REG, KT) WG_DMA(wrs4, woff, wlds, REG, KT)
-#define WG_DMA_X(REG, KT) WG_DMA(xrs4, xoff, xlds, REG, KT)
+    WG_SEEK(c0, 0, 0) WG_SEEK(c1, 1, 0)
+#define WG_ADVANCE(P, R)                                                                          \
+    { P##_par ^= 1u; if (++P##_kt == P##_kend) WG_SEEK(P, R, P##_seq + 1) }
+#define WG_PIECES(P, RS4, LDS, R, OFF0, OFF1)                                                     \
+    {                                                                                             \
+        const unsigned kb_ = (unsigned)P##_kt * (unsigned)ROWB, bo_ = P##_par * (unsigned)BUF_B;  \
+        dma_piece(RS4, LDS(R, 0) + bo_, P##OFF0 + kb_);                                           \
+        dma_piece(RS4, LDS(R, 1) + bo_, P##OFF1 + kb_);                                           \
+    }
+#define WG_DMA_W0() WG_PIECES(c0, wrs4, WG_WLDS, 0, _w0, _w1)
+#define WG_DMA_X0() WG_PIECES(c0, xrs4, WG_XLDS, 0, _x0, _x1)
+#define WG_DMA_W1() WG_PIECES(c1, wrs4, WG_WLDS, 1, _w0, _w1)
+#define WG_DMA_X1() WG_PIECES(c1, xrs4, WG_XLDS, 1, _x0, _x1)
 
     // ---- fragment addresses: lane reads row frow of a 16-row tile, chunk (ks * 4 + kq) ^ (frow & 7) ----
     const int frow = lane & 15, kq = lane >> 4;
@@ -126,11 +171,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, int tiles
     const unsigned char* const xfb = wsm + TILE_B + (wc * 64) * ROWB;
 
     floatx4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
     bf16x8 wf[4][2], xa[2][2], xb[2][2];
+    const floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
 #define WG_READ_W(I0)                                                                             \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
@@ -142,14 +184,22 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, int tiles
         XF[j][0] = *(const bf16x8*)(xp_ + ((J0) + j) * (16 * ROWB) + fo0);                        \
         XF[j][1] = *(const bf16x8*)(xp_ + ((J0) + j) * (16 * ROWB) + fo1);                        \
     }
-#define WG_MMA(I0, J0, XF)                                                                        \
+    // ZERO: first K step of an item - the ks = 0 MFMA starts from the inline constant 0 (no clearing pass)
+#define WG_MMA(I0, J0, XF, ZERO)                                                                  \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                         \
-                acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], XF[j][ks], acc[(I0) + i][(J0) + j], 0, 0, 0);
+                acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], XF[j][ks], \
+                    ((ZERO) && ks == 0) ? zero4 : acc[(I0) + i][(J0) + j], 0, 0, 0);
     // end of a load segment: retire the region the next phase reads, meet, wait for this phase's fragments
-#define WG_TO_MMA()                                                                               \
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                              \
+#define WG_WAIT_8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // first K step of an item: the previous item's epilogue stores (16, or 32 partial-sum stores) may stay in flight
+#define WG_WAIT_SEL()                                                                             \
+    if (vmsel == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                              \
+    else if (vmsel == 1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                        \
+    else asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+#define WG_TO_MMA(WAIT)                                                                           \
+    WAIT()                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                            \
     __builtin_amdgcn_s_barrier();                                                                 \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
@@ -160,176 +210,285 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, int tiles
     __builtin_amdgcn_sched_barrier(0);                                                            \
     __builtin_amdgcn_s_barrier();                                                                 \
     __builtin_amdgcn_sched_barrier(0);
+    // one K step = four phases; VM = operations that may stay outstanding at the end of a load segment
+#define WG_KSTEP(ZERO, VM)                                                                        \
+    {                                                                                             \
+        const unsigned char* const wp_ = wfb + rpar * BUF_B;                                      \
+        const unsigned char* const xp_ = xfb + rpar * BUF_B;                                      \
+        WG_READ_W(0) WG_READ_X(xa, 0)                                                             \
+        WG_DMA_X1()                                                                               \
+        WG_TO_MMA(VM)                                                                             \
+        WG_MMA(0, 0, xa, ZERO)                                                                    \
+        WG_TO_LOAD()                                                                              \
+        WG_READ_X(xb, 2)                                                                          \
+        WG_DMA_W1()                                                                               \
+        WG_TO_MMA(VM)                                                                             \
+        WG_MMA(0, 2, xb, ZERO)                                                                    \
+        WG_TO_LOAD()                                                                              \
+        WG_READ_W(4)                                                                              \
+        WG_DMA_W0()                                                                               \
+        WG_TO_MMA(VM)                                                                             \
+        WG_MMA(4, 2, xb, ZERO)                                                                    \
+        WG_TO_LOAD()                                                                              \
+        WG_DMA_X0()                                                                               \
+        WG_TO_MMA(VM)                                                                             \
+        WG_MMA(4, 0, xa, ZERO)                                                                    \
+        WG_TO_LOAD()                                                                              \
+        rpar ^= 1u;                                                                               \
+        WG_ADVANCE(c1, 1) WG_ADVANCE(c0, 0)                                                       \
+    }
 
-    // ---- prologue: all of K tile 0, and the two regions of tile 1 that phases 2-3 of a tile issue ----
-    WG_DMA_W(0, 0) WG_DMA_X(0, 0) WG_DMA_X(1, 0) WG_DMA_W(1, 0)
-    WG_DMA_W(0, 1) WG_DMA_X(0, 1)
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // filter region 0 and pixel region 0 of tile 0 have landed
+    // ---- prologue: all of the first K step, and the two regions of the second that phases 2-3 of a step issue ----
+    WG_DMA_W0() WG_DMA_X0() WG_DMA_X1() WG_DMA_W1()
+    WG_ADVANCE(c0, 0) WG_ADVANCE(c1, 1)
+    WG_DMA_W0() WG_DMA_X0()
+    WG_ADVANCE(c0, 0)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // filter region 0 and pixel region 0 of step 0 have landed
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();           // waves 4-7 run one barrier behind
 
-    for (int t = 0; t < nk; ++t) {
-        const unsigned char* const wp_ = wfb + (t & 1) * BUF_B;
-        const unsigned char* const xp_ = xfb + (t & 1) * BUF_B;
-        // phase 0: quadrant (channel tiles 0-3, pixel tiles 0-1)
-        WG_READ_W(0) WG_READ_X(xa, 0)
-        WG_DMA_X(1, t + 1)
-        WG_TO_MMA()
-        WG_MMA(0, 0, xa)
-        WG_TO_LOAD()
-        // phase 1: quadrant (0-3, 2-3)
-        WG_READ_X(xb, 2)
-        WG_DMA_W(1, t + 1)
-        WG_TO_MMA()
-        WG_MMA(0, 2, xb)
-        WG_TO_LOAD()
-        // phase 2: quadrant (4-7, 2-3)
-        WG_READ_W(4)
-        WG_DMA_W(0, t + 2)
-        WG_TO_MMA()
-        WG_MMA(4, 2, xb)
-        WG_TO_LOAD()
-        // phase 3: quadrant (4-7, 0-1); its operands are in registers already
-        WG_DMA_X(0, t + 2)
-        WG_TO_MMA()
-        WG_MMA(4, 0, xa)
-        WG_TO_LOAD()
+    const bool gelu_bwd = a.mode == 1 && a.epi == 5;
+    const void* pre_src = gelu_bwd ? a.ep_src : a.addend;
+    const unsigned ybytes = (unsigned)M * (unsigned)Nn * 2u;
+    const int q4 = kq * 4;
+    unsigned rpar = 0u;
+    int vmsel = 0;
+
+    const int row = kq;                                               // 16-lane row of this lane
+    const bool plain_epi = a.bias == nullptr && a.act == 0 && pre_src == nullptr;
+#define WG_EPILOGUE(GENERAL)                                                                      \
+    {                                                                                             \
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (g.dbg & 1) ? 0u : ybytes, 0x00020000); \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+            const int px = m0 + j * 16 + frow;                                                    \
+            unsigned eo[4];                                                                       \
+            u32x4 pre[4];                                                                         \
+            unsigned pmk[4];                                                                      \
+            _Pragma("unroll") for (int ip = 0; ip < 4; ++ip) {                                    \
+                const int ch = c0 + 16 * (2 * ip + (row & 1)) + 8 * (row >> 1);                   \
+                eo[ip] = (px < M && ch < Nn) ? (unsigned)px * (unsigned)Nn + (unsigned)ch : ~0u;  \
+            }                                                                                     \
+            if ((GENERAL) && pre_src != nullptr) {                                                \
+                const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)pre_src, 0, ybytes, 0x00020000); \
+                _Pragma("unroll") for (int ip = 0; ip < 4; ++ip)                                  \
+                    pre[ip] = __builtin_amdgcn_raw_buffer_load_b128(srs, eo[ip] != ~0u ? eo[ip] * 2u : 0xFFFFFFF0u, 0, 0); \
+                if (!gelu_bwd && a.addend_mask != nullptr) {                                      \
+                    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.addend_mask, 0, ybytes >> 4, 0x00020000); \
+                    _Pragma("unroll") for (int ip = 0; ip < 4; ++ip)                              \
+                        pmk[ip] = __builtin_amdgcn_raw_buffer_load_b8(mrs, eo[ip] != ~0u ? eo[ip] >> 3 : 0xFFFFFFF0u, 0, 0); \
+                } else {                                                                          \
+                    _Pragma("unroll") for (int ip = 0; ip < 4; ++ip) pmk[ip] = 0xFFu;             \
+                }                                                                                 \
+            }                                                                                     \
+            _Pragma("unroll") for (int ip = 0; ip < 4; ++ip) {                                    \
+                unsigned d[2][2];                                                                 \
+                _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                   \
+                    const int i = 2 * ip + h;                                                     \
+                    float v[4];                                                                   \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];            \
+                    if (GENERAL) {                                                                \
+                        if (a.bias != nullptr) {                                                  \
+                            const int ch = c0 + i * 16 + q4;                                      \
+                            _Pragma("unroll") for (int r = 0; r < 4; ++r) v[r] += a.bias[min(ch + r, Nn - 1)]; \
+                        }                                                                         \
+                        if (a.act == 1) {                                                         \
+                            _Pragma("unroll") for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); \
+                        } else if (a.act == 2) {                                                  \
+                            _Pragma("unroll") for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast(v[r]); \
+                        }                                                                         \
+                    }                                                                             \
+                    d[h][0] = pack_bf16x2(v[0], v[1]);                                            \
+                    d[h][1] = pack_bf16x2(v[2], v[3]);                                            \
+                }                                                                                 \
+                /* odd rows of the first operand <-> even rows of the second: afterwards a lane in row r holds channels */ \
+                /* 16 * (2 ip + (r & 1)) + 8 * (r >> 1) .. + 7 of its pixel as (s0[0], s1[0], s0[1], s1[1]) */ \
+                const u32x2 s0 = __builtin_amdgcn_permlane16_swap(d[0][0], d[1][0], false, false); \
+                const u32x2 s1 = __builtin_amdgcn_permlane16_swap(d[0][1], d[1][1], false, false); \
+                uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);                                 \
+                if ((GENERAL) && pre_src != nullptr) {                                            \
+                    float f[8], gx[8];                                                            \
+                    unpack8(v, f); unpack8(__builtin_bit_cast(uint4, pre[ip]), gx);               \
+                    if (gelu_bwd) {                                                               \
+                        _Pragma("unroll") for (int e = 0; e < 8; ++e) f[e] *= gelu_tanh_grad_fast(gx[e]); \
+                    } else {                                                                      \
+                        const unsigned mk = pmk[ip];                                              \
+                        _Pragma("unroll") for (int e = 0; e < 8; ++e) f[e] += ((mk >> e) & 1u) ? gx[e] : 0.f; \
+                    }                                                                             \
+                    v = pack8(f);                                                                 \
+                }                                                                                 \
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, yrs, eo[ip] != ~0u ? eo[ip] * 2u : 0xFFFFFFF0u, 0, 0); \
+            }                                                                                     \
+        }                                                                                         \
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tail pieces (zeros) must land before LDS is reused
+
+    for (int seq = 0; seq < nseq; ++seq) {
+        int tm, tn, z;
+        item_coords(seq, tm, tn, z);
+        const int k0 = z * g.nks, steps = min(nk, k0 + g.nks) - k0;
+        WG_KSTEP(true, WG_WAIT_SEL)
+        for (int s = 1; s < steps; ++s) WG_KSTEP(false, WG_WAIT_8)
+        vmsel = g.splitk == 1 ? 1 : 2;
+
+        // Both wave groups write their tile out in the SAME barrier interval: waves 0-3 (one barrier ahead) sit out the
+        // interval in which waves 4-7 issue their last MFMAs, and waves 4-7 drop back behind afterwards.  Left staggered,
+        // each group's write-out (~4k cycles of VALU and store issue) held the other group at its next barrier: twice
+        // the cost per item.
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int m0 = tm * 256 + wc * 64, c0 = tn * 256 + wr * 128;
+        if (g.splitk > 1) {
+            // ---- partial sums: this lane's 4 consecutive channels of a pixel = one 16-byte fp32 store ----
+            float* const slab = g.ws + (size_t)z * (size_t)M * (size_t)Nn;
+            const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (unsigned)M * (unsigned)Nn * 4u, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int px = m0 + j * 16 + frow;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int ch = c0 + i * 16 + q4;
+                    const unsigned off = (px < M && ch < Nn) ? ((unsigned)px * (unsigned)Nn + (unsigned)ch) * 4u : 0xFFFFFFF0u;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), prs, off, 0, 0);
+                }
+            }
+        } else
+        // ---- epilogue from registers: bias / activation in fp32, pack, pair adjacent channel tiles so that a
+        //      lane holds 8 consecutive channels: 16 range-checked 16-byte stores per lane, no branches.
+        //      Expanded once for the plain tile (BatchNorm-free GEMMs: the LM head) and once in general form ----
+        if (plain_epi) WG_EPILOGUE(false)
+        else           WG_EPILOGUE(true)
+        __builtin_amdgcn_sched_barrier(0);
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the run-ahead pieces (zeros) must land before the LDS is released
     if (wr == 0) __builtin_amdgcn_s_barrier();           // waves 0-3 catch up: barrier counts are equal again
     __syncthreads();
 
-#undef WG_DMA
-#undef WG_DMA_W
-#undef WG_DMA_X
+#undef WG_ADVANCE
+#undef WG_EPILOGUE
+#undef WG_SEEK
+#undef WG_WROW
+#undef WG_XROW
+#undef WG_WLDS
+#undef WG_XLDS
+#undef WG_PIECES
+#undef WG_WAIT_8
+#undef WG_WAIT_SEL
+#undef WG_DMA_W0
+#undef WG_DMA_W1
+#undef WG_DMA_X0
+#undef WG_DMA_X1
 #undef WG_READ_W
 #undef WG_READ_X
 #undef WG_MMA
 #undef WG_TO_MMA
 #undef WG_TO_LOAD
+#undef WG_KSTEP
+}
 
-    // ---- epilogue: bias / activation in fp32, stage the wave's 64 x 128 bf16 tile in its own LDS region ----
-    unsigned char* const cs = wsm + wave * EPI_WAVE_B;
-    const int q4 = kq * 4;
-    if (a.bias == nullptr && a.act == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint2 pk;
-                pk.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
-                pk.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
-                *(uint2*)(cs + (j * 16 + frow) * EPI_ROWB + (i * 16 + q4) * 2) = pk;
-            }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int ch = c0 + wr * 128 + i * 16 + q4;
-            float b[4] = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias != nullptr) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) b[r] = a.bias[min(ch + r, Nn - 1)];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float tv = acc[i][j][r] + b[r];
-                    if (a.act == 1) tv = fmaxf(tv, 0.f);
-                    else if (a.act == 2) tv = gelu_tanh(tv);
-                    v[r] = tv;
-                }
-                uint2 pk;
-                pk.x = pack_bf16x2(v[0], v[1]);
-                pk.y = pack_bf16x2(v[2], v[3]);
-                *(uint2*)(cs + (j * 16 + frow) * EPI_ROWB + (i * 16 + q4) * 2) = pk;
-            }
-        }
-    }
-    // the region is private to the wave: LDS executes a wave's accesses in order, so no barrier - only
-    // keep the compiler from moving the reads above the writes
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- write-out: lane = (row % 4, 16-byte chunk); 16 passes of 4 pixel rows x 256 B ----
-    const int och = lane & 15, orow = lane >> 4;
-    const int co = c0 + wr * 128 + och * 8;
-    const bool cok = co < Nn;                               // Nn % 8 == 0 (host check)
-    unsigned short* const yg = (unsigned short*)a.y;
+// Fold the split-K slabs in a fixed order and apply the epilogue: one thread = 8 consecutive channels of a pixel.
+__global__ __launch_bounds__(256) void gemm_splitk_fold_kernel(ConvArgs a, const float* __restrict__ ws, int splitk, long MN, int Nn) {
     const bool gelu_bwd = a.mode == 1 && a.epi == 5;
     const void* pre_src = gelu_bwd ? a.ep_src : a.addend;
-    const unsigned ybytes = (unsigned)M * (unsigned)Nn * 2u;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        unsigned eoff[8];
-        u32x4 pre[8];
-        unsigned pmk[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int px = m0 + wc * 64 + (half * 8 + s) * 4 + orow;
-            eoff[s] = (px < M && cok) ? (unsigned)px * (unsigned)Nn + (unsigned)co : ~0u;
+    for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 8; e < MN; e += (long)gridDim.x * 256 * 8) {
+        float f[8];
+        {
+            const float4 p0 = *(const float4*)(ws + e), p1 = *(const float4*)(ws + e + 4);
+            f[0] = p0.x; f[1] = p0.y; f[2] = p0.z; f[3] = p0.w; f[4] = p1.x; f[5] = p1.y; f[6] = p1.z; f[7] = p1.w;
         }
+        for (int z = 1; z < splitk; ++z) {
+            const float4 p0 = *(const float4*)(ws + z * MN + e), p1 = *(const float4*)(ws + z * MN + e + 4);
+            f[0] += p0.x; f[1] += p0.y; f[2] += p0.z; f[3] += p0.w; f[4] += p1.x; f[5] += p1.y; f[6] += p1.z; f[7] += p1.w;
+        }
+        const int ch = (int)(e % Nn);
+        if (a.bias != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += a.bias[ch + j];
+        }
+        if (a.act == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
+        } else if (a.act == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = gelu_tanh(f[j]);
+        }
+        uint4 v = pack8(f);
         if (pre_src != nullptr) {
-            const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)pre_src, 0, ybytes, 0x00020000);
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
-                pre[s] = __builtin_amdgcn_raw_buffer_load_b128(srs, eoff[s] != ~0u ? eoff[s] * 2u : 0xFFFFFFF0u, 0, 0);
-            if (!gelu_bwd && a.addend_mask != nullptr) {
-                const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.addend_mask, 0, ybytes >> 4, 0x00020000);
-#pragma unroll
-                for (int s = 0; s < 8; ++s)
-                    pmk[s] = __builtin_amdgcn_raw_buffer_load_b8(mrs, eoff[s] != ~0u ? eoff[s] >> 3 : 0xFFFFFFF0u, 0, 0);
-            } else {
-#pragma unroll
-                for (int s = 0; s < 8; ++s) pmk[s] = 0xFFu;
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            if (eoff[s] == ~0u) continue;
-            const int row = (half * 8 + s) * 4 + orow;
-            uint4 v = *(const uint4*)(cs + row * EPI_ROWB + och * 16);
+            float gx[8];
+            unpack8(v, f); unpack8(*(const uint4*)((const unsigned short*)pre_src + e), gx);
             if (gelu_bwd) {
-                float f[8], g[8];
-                unpack8(v, f); unpack8(__builtin_bit_cast(uint4, pre[s]), g);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] *= gelu_tanh_grad_fast(g[j]);
-                v = pack8(f);
-            } else if (pre_src != nullptr) {
-                float f[8], g[8];
-                unpack8(v, f); unpack8(__builtin_bit_cast(uint4, pre[s]), g);
-                const unsigned mk = pmk[s];
+                for (int j = 0; j < 8; ++j) f[j] *= gelu_tanh_grad_fast(gx[j]);
+            } else {
+                const unsigned mk = a.addend_mask != nullptr ? a.addend_mask[e >> 3] : 0xFFu;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] += ((mk >> j) & 1u) ? g[j] : 0.f;
-                v = pack8(f);
+                for (int j = 0; j < 8; ++j) f[j] += ((mk >> j) & 1u) ? gx[j] : 0.f;
             }
-            *(uint4*)(yg + (size_t)eoff[s]) = v;
-            if (a.mode == 0 && a.y_act != nullptr) {
-                float f[8];
-                unpack8(v, f);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] = gelu_tanh(f[j]);
-                *(uint4*)((unsigned short*)a.y_act + (size_t)eoff[s]) = pack8(f);
-            }
+            v = pack8(f);
         }
+        *(uint4*)((unsigned short*)a.y + e) = v;
     }
 }
 
 int g_wide_min_tiles = -1;      // -1: not yet read from the environment
+int g_wide_splitk = -1;         // -1: not yet read; 0 = choose per launch; n > 0 = force
+
+// grow-only fp32 workspace per stream (two streams may run split-K GEMMs side by side)
+struct Workspace { float* ptr = nullptr; size_t bytes = 0; };
+std::mutex g_ws_mutex;
+std::unordered_map<hipStream_t, Workspace> g_ws;
+
+float* workspace_for(hipStream_t st, size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    Workspace& w = g_ws[st];
+    if (w.bytes < bytes) {
+        if (w.ptr != nullptr) { (void)hipStreamSynchronize(st); (void)hipFree(w.ptr); }
+        w.ptr = nullptr; w.bytes = 0;
+        if (hipMalloc((void**)&w.ptr, bytes) != hipSuccess) {
+            fprintf(stderr, "gemm_wide: cannot allocate %zu bytes of split-K workspace\n", bytes);
+            abort();
+        }
+        w.bytes = bytes;
+    }
+    return w.ptr;
+}
+
+// Split factor of a launch: a cost model in microseconds calibrated on scripts/one_gemm.py (1.35 us per K step per
+// workgroup, ~1 us per item, slabs written and read back at ~4 TB/s); 1 = no split.
+int choose_splitk(long tiles, int nk, long MN) {
+    if (g_wide_splitk < 0) {
+        const char* e = getenv("DPA_WIDE_SPLITK");
+        g_wide_splitk = e ? atoi(e) : 0;
+        if (g_wide_splitk < 0) g_wide_splitk = 0;
+    }
+    int lo = 1, hi = 16;
+    if (g_wide_splitk > 0) lo = hi = g_wide_splitk;
+    double best = 1e30;
+    int best_s = 1;
+    for (int s = lo; s <= hi; ++s) {
+        const int nks = (nk + s - 1) / s;
+        if (s > 1 && ((long)(s - 1) * nks >= nk || nks < 4)) continue;     // every split non-empty and worth an item
+        if (s > 1 && (double)s * MN * 4.0 >= 4.0e9) continue;
+        const long rounds = (tiles * s + 255) / 256;
+        double t = rounds * (nks * 1.35 + 1.0);
+        if (s > 1) t += (s + 0.5) * MN * 4.0 / 4.0e6;
+        if (t < best * 0.97) { best = t; best_s = s; }
+    }
+    return best_s;
+}
 
 }  // namespace
 
-// Smallest number of 256 x 256 tiles for which conv_igemm() prefers this kernel (DPA_WIDE_MIN_TILES; 0 = never).
+// Smallest number of 256 x 256 work items for which conv_igemm() prefers this kernel (DPA_WIDE_MIN_TILES; 0 = never).
 void set_wide_gemm_min_tiles(int n) { g_wide_min_tiles = n < 0 ? 0 : n; }
 int wide_gemm_min_tiles() {
     if (g_wide_min_tiles < 0) {
         const char* e = getenv("DPA_WIDE_MIN_TILES");
-        g_wide_min_tiles = e ? atoi(e) : 300;
+        g_wide_min_tiles = e ? atoi(e) : 180;
         if (g_wide_min_tiles < 0) g_wide_min_tiles = 0;
     }
     return g_wide_min_tiles;
 }
+void set_wide_gemm_splitk(int n) { g_wide_splitk = n < 0 ? 0 : n; }
 
 // A launch the wide kernel can take: a plain GEMM (1x1, stride 1, no padding) with K a multiple of 64, one of the
 // epilogues implemented above, operands addressable by 31-bit byte offsets.
@@ -337,19 +496,28 @@ bool wide_gemm_supported(const ConvArgs& a) {
     if (!(a.R == 1 && a.S == 1 && a.pad == 0 && a.stride == 1)) return false;
     if (a.mode != 0 && a.mode != 1) return false;
     if (a.C % WBK != 0 || a.K % 8 != 0 || a.y == nullptr) return false;
-    if (a.stats != nullptr) return false;
+    if (a.stats != nullptr || a.y_act != nullptr) return false;
     if (!(a.epi == 0 || (a.mode == 1 && a.epi == 5))) return false;
     const long M = (long)a.N * a.Ho * a.Wo;
     if (M * a.C * 2 >= (1l << 31) || (long)a.K * a.C * 2 >= (1l << 31) || M * a.K >= (1l << 31) - 16) return false;
     return true;
 }
 
+// Where the wide kernel wins (scripts/bench_gemm.py, one process, both kernels on the same operands): deep K
+// (>= 768: the per-item cost - a 128-KiB store burst per CU that in-order vmcnt cannot hide - is amortised over >= 12
+// K steps) and enough items to fill the chip; split K only for very deep K (the LM head's input gradient).  The
+// thresholds are lifted by set_wide_gemm_min_tiles(1) (tests: every supported launch).
 bool wide_gemm_eligible(const ConvArgs& a) {
     const int min_tiles = wide_gemm_min_tiles();
     if (min_tiles <= 0 || !wide_gemm_supported(a)) return false;
     const long M = (long)a.N * a.Ho * a.Wo;
     const long tiles = ((M + 255) / 256) * ((a.K + 255) / 256);
-    return tiles >= min_tiles;
+    const int nk = a.C / WBK;
+    const int s = choose_splitk(tiles, nk, M * a.K);
+    if (min_tiles == 1) return true;
+    if (nk < 12) return false;
+    if (s > 1 && nk < 96) return false;
+    return tiles * s >= min_tiles;
 }
 
 void gemm_wide(const ConvArgs& a, hipStream_t st) {
@@ -367,8 +535,29 @@ void gemm_wide(const ConvArgs& a, hipStream_t st) {
         allowed = true;
     }
     const long M = (long)a.N * a.Ho * a.Wo;
-    const int tiles_m = (int)((M + 255) / 256), tiles_n = (a.K + 255) / 256;
-    hipLaunchKernelGGL(gemm_wide_kernel, dim3(tiles_m * tiles_n), dim3(512), WIDE_LDS, st, a, tiles_m, tiles_n, (int)M, a.C);
+    WideArgs g{};
+    g.tiles_m = (int)((M + 255) / 256); g.tiles_n = (a.K + 255) / 256;
+    g.M = (int)M; g.Kd = a.C;
+    const int nk = a.C / WBK;
+    const long tiles = (long)g.tiles_m * g.tiles_n;
+    g.splitk = choose_splitk(tiles, nk, M * a.K);
+    g.nks = (nk + g.splitk - 1) / g.splitk;
+    g.items = (int)(tiles * g.splitk);
+    {
+        static const int skew_on = [] { const char* e = getenv("DPA_WIDE_SKEW"); return e ? atoi(e) : 1; }();
+        // one item = nks K steps of ~2,700 cycles; spread the starts over one item when every workgroup has several
+        g.skew = (skew_on && g.items >= 3 * 256) ? (int)((long)g.nks * 2700 * skew_on / 8128) : 0;
+    }
+    { static const int dbg = [] { const char* e = getenv("DPA_WIDE_DBG"); return e ? atoi(e) : 0; }(); g.dbg = dbg; }
+    g.ws = g.splitk > 1 ? workspace_for(st, (size_t)g.splitk * (size_t)M * (size_t)a.K * 4) : nullptr;
+    const int grid = g.items < 256 ? g.items : 256;
+    hipLaunchKernelGGL(gemm_wide_kernel, dim3(grid), dim3(512), WIDE_LDS, st, a, g);
+    if (g.splitk > 1) {
+        const long MN = M * a.K;
+        long blocks = (MN / 8 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(gemm_splitk_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, (const float*)g.ws, g.splitk, MN, a.K);
+    }
 }
 
 }  // namespace dpa

@@ -53,6 +53,7 @@ bool wide_gemm_supported(const ConvArgs& a);
 bool wide_gemm_eligible(const ConvArgs& a);
 void gemm_wide(const ConvArgs& a, hipStream_t st);
 void set_wide_gemm_min_tiles(int n);
+void set_wide_gemm_splitk(int n);   // 0 = chosen per launch by a cost model, n > 0 = forced (tests)
 int wide_gemm_min_tiles();
 
 // wgrad: dw[k,r,s,c] += sum_{n,ho,wo} dy[n,ho,wo,k] * x[n, ho*stride-pad+r, wo*stride-pad+s, c]

@@ -94,6 +94,8 @@ class Embedding(nn.Module):
         self.wpe = nn.Parameter(torch.randn(cfg.n_positions, cfg.n_embd) * 0.01)
         self.wte_lp = None
         self.wpe_lp = None
+        self.wte_lp_t = None               # bf16 [n_embd, vocab] twin for the tied head's input gradient (FlatParams)
+        self._dpa_twins = ("wte",)
         self._dpa_tie = ("wte", "first")   # pipeline: this matrix also lives in the LM-head stage (parallel/pp.py)
 
     def forward(self, tokens):
@@ -120,7 +122,7 @@ class GPT2(nn.Module):
     def forward(self, tokens: torch.Tensor) -> torch.Tensor:
         """Logits ``[B, T, vocab_padded]`` (tied LM head; columns >= vocab_size are padding)."""
         x = self.hidden(tokens)
-        return ops.linear(x, self.emb.wte, self.emb.wte_lp, None, plain=True)
+        return ops.linear(x, self.emb.wte, self.emb.wte_lp, None, weight_lp_t=self.emb.wte_lp_t)
 
     def loss(self, tokens: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
         logits = self.forward(tokens)
@@ -142,10 +144,12 @@ class _LMHead(nn.Module):
         self.ln_f = model.ln_f
         self.wte = model.emb.wte
         self.wte_lp = None                 # bound by FlatParams, like Embedding.wte_lp
+        self.wte_lp_t = None               # ... and the [n_embd, vocab] twin the head's input gradient multiplies by
+        self._dpa_twins = ("wte",)
         self._dpa_tie = ("wte", "last")
 
     def forward(self, x):
-        return ops.linear(self.ln_f(x), self.wte, self.wte_lp, None, plain=True)
+        return ops.linear(self.ln_f(x), self.wte, self.wte_lp, None, weight_lp_t=self.wte_lp_t)
 
 
 def gpt2_small() -> GPT2:

@@ -115,67 +115,21 @@ def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, weight_lp: Optional[torch
     return y.permute(0, 2, 3, 1).contiguous(), None
 
 
-LIBRARY_PLAIN_GEMM = os.environ.get("DPA_LM_HEAD", "lib") != "own"
-
-
-class _PlainLinearFn(torch.autograd.Function):
-    """``y = x @ w^T`` with NOTHING fused (no bias, no epilogue, no statistics): the one GEMM shape here that is a plain
-    library GEMM - the tied LM head, 8192 x 50304 x 768.  The 128x128-tile kernel of conv_igemm.hip is L2-bandwidth
-    bound around 0.7 PFLOP/s (64 FLOP per staged byte); on that shape hipBLASLt's wider tiles reach 1.15 PFLOP/s
-    (scripts/bench_gemm.py, WITH_LIB=1: 551 vs 953 us forward, 558 vs 995 us input gradient) and need no transposed
-    copy of the 77 MB matrix.  The weight gradient stays on conv_wgrad.hip (696 vs 651 us, and it accumulates straight
-    into the flat gradient buffer on the side stream, which a library call cannot)."""
-
-    @staticmethod
-    def forward(ctx, x2, weight, weight_lp):
-        w = _lp(weight, weight_lp)
-        ctx.save_for_backward(x2, w)
-        ctx.weight = weight
-        return torch.matmul(x2, w.t())
-
-    @staticmethod
-    def backward(ctx, dy):
-        C = _ext.load()
-        x2, w = ctx.saved_tensors
-        dy = dy.contiguous()
-        weight = ctx.weight
-        dx = dw = None
-        M, cin, cout = x2.shape[0], w.shape[1], w.shape[0]
-        x4, dy4 = x2.view(M, 1, 1, cin), dy.view(M, 1, 1, cout)
-        if weight.requires_grad:      # before the input gradient: the two GEMMs share dy and run side by side
-            tgt = _sink.target(weight)
-            if tgt is not None:
-                tv = tgt.view(cout, 1, 1, cin)
-                if _side.active(x2):
-                    _side.run(lambda: C.conv_wgrad(x4, dy4, tv, 1, 0, None), (x2, dy))
-                else:
-                    C.conv_wgrad(x4, dy4, tv, 1, 0, None)
-                _sink.ready(weight)
-            else:
-                dw = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)
-                C.conv_wgrad(x4, dy4, dw.view(cout, 1, 1, cin), 1, 0, None)
-        if ctx.needs_input_grad[0]:
-            dx = torch.matmul(dy, w)
-        return dx, dw, None
-
-
 def linear(x: torch.Tensor, weight: torch.Tensor, weight_lp: Optional[torch.Tensor] = None,
            bias: Optional[torch.Tensor] = None, weight_lp_t: Optional[torch.Tensor] = None,
-           residual: Optional[torch.Tensor] = None, pre_gelu: bool = False, plain: bool = False,
+           residual: Optional[torch.Tensor] = None, pre_gelu: bool = False,
            gelu_twin: bool = False, gelu_act: Optional[torch.Tensor] = None):
     """``y = x @ weight^T + bias (+ residual)`` with ``weight [out, in]``; any leading dims on ``x``.
     ``weight_lp_t`` is the optional bf16 ``[in, out]`` twin the input gradient multiplies by; ``residual`` (the
     output's shape) is added in the GEMM epilogue; ``pre_gelu``: ``y = gelu_tanh(x) @ weight^T ...`` with the GELU's
     backward folded into the input-gradient GEMM's epilogue; ``gelu_twin``: returns ``(y, gelu_tanh(y))``, the second
     written by the same epilogue (None off the GPU) - hand it to the next layer as ``gelu_act`` with ``pre_gelu``.
-    ``plain``: the caller fuses nothing into this GEMM and
-    it is large (the LM head) - forward and input gradient may go to the library GEMM (see _PlainLinearFn)."""
+    Every GEMM runs on this repository's own kernels: csrc/conv_igemm.hip (128 x 128 tiles) or, for large launches
+    such as the tied LM head (8192 x 50304 x 768 forward, 8192 x 768 x 50304 split-K input gradient),
+    csrc/gemm_wide.hip (persistent 256 x 256 tiles); no vendor BLAS is called."""
     if _ext.use_hip(x):
         lead = x.shape[:-1]
         cin, cout = weight.shape[1], weight.shape[0]
-        if plain and LIBRARY_PLAIN_GEMM and bias is None and residual is None and not pre_gelu:
-            y = _PlainLinearFn.apply(x.reshape(-1, cin).contiguous(), weight, weight_lp)
-            return y.reshape(*lead, cout)
         x4 = x.reshape(-1, 1, 1, cin)
         wt = None if weight_lp_t is None else weight_lp_t.view(cin, 1, 1, cout)
         r4 = None if residual is None else residual.contiguous().reshape(-1, 1, 1, cout)

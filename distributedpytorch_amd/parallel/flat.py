@@ -76,13 +76,16 @@ class FlatParams:
         self._tr_table = None
         self._tr_tiles = 0
         if self.lp is not None:
-            rows, tiles = [], 0
+            rows, tiles, done = [], 0, set()
             for mod in module.modules():
-                w = getattr(mod, "weight", None)
-                if hasattr(mod, "weight_lp_t") and isinstance(w, nn.Parameter) and w.dim() in (2, 4):
+                for pname in self._twin_names(mod):
+                    w = getattr(mod, pname, None)
+                    if not isinstance(w, nn.Parameter) or w.dim() not in (2, 4) or id(w) in done:
+                        continue
                     i = next((k for k, q in enumerate(self.params) if q is w), None)
                     if i is None:
                         continue
+                    done.add(id(w))                 # a tied matrix (GPT-2 wte) is transposed once
                     K, R, S, C = w.shape if w.dim() == 4 else (w.shape[0], 1, 1, w.shape[1])   # Linear [out,in] = K,1,1,C
                     rows.append([offsets[i], offsets[i], K, R * S, C, tiles])
                     tiles += ((K + 31) // 32) * ((C + 31) // 32) * R * S
@@ -92,6 +95,15 @@ class FlatParams:
                 self._tr_tiles = tiles
         self.refresh_lp()
         self._bind_shadows()
+
+    @staticmethod
+    def _twin_names(mod: nn.Module):
+        """Parameters of ``mod`` that want a transposed bf16 twin ``<name>_lp_t``: ``weight`` when the module has a
+        ``weight_lp_t`` attribute, plus whatever it lists in ``_dpa_twins`` (GPT-2's tied embedding matrix)."""
+        names = list(getattr(mod, "_dpa_twins", ()))
+        if hasattr(mod, "weight_lp_t") and "weight" not in names:
+            names.append("weight")
+        return names
 
     # ------------------------------------------------------------------ views
     def slice_of(self, p: nn.Parameter) -> Tuple[int, int]:
@@ -118,12 +130,12 @@ class FlatParams:
                     i = index[id(p)]
                     off = self.offsets[i]
                     setattr(mod, attr, self.lp[off:off + p.numel()].view(p.shape))
-                    if pname == "weight" and self.lp_t is not None and hasattr(mod, "weight_lp_t") and p.dim() in (2, 4):
+                    if self.lp_t is not None and pname in self._twin_names(mod) and p.dim() in (2, 4):
                         if p.dim() == 4:
                             K, R, S, C = p.shape
-                            mod.weight_lp_t = self.lp_t[off:off + p.numel()].view(C, R, S, K)
+                            setattr(mod, pname + "_lp_t", self.lp_t[off:off + p.numel()].view(C, R, S, K))
                         else:
-                            mod.weight_lp_t = self.lp_t[off:off + p.numel()].view(p.shape[1], p.shape[0])
+                            setattr(mod, pname + "_lp_t", self.lp_t[off:off + p.numel()].view(p.shape[1], p.shape[0]))
 
     def refresh_lp(self) -> None:
         if self.lp is None:
