@@ -483,7 +483,7 @@ void set_wide_gemm_min_tiles(int n) { g_wide_min_tiles = n < 0 ? 0 : n; }
 int wide_gemm_min_tiles() {
     if (g_wide_min_tiles < 0) {
         const char* e = getenv("DPA_WIDE_MIN_TILES");
-        g_wide_min_tiles = e ? atoi(e) : 180;
+        g_wide_min_tiles = e ? atoi(e) : 700;
         if (g_wide_min_tiles < 0) g_wide_min_tiles = 0;
     }
     return g_wide_min_tiles;
@@ -506,7 +506,11 @@ bool wide_gemm_supported(const ConvArgs& a) {
 // Where the wide kernel wins (scripts/bench_gemm.py, one process, both kernels on the same operands): deep K
 // (>= 768: the per-item cost - a 128-KiB store burst per CU that in-order vmcnt cannot hide - is amortised over >= 12
 // K steps) and enough items to fill the chip; split K only for very deep K (the LM head's input gradient).  The
-// thresholds are lifted by set_wide_gemm_min_tiles(1) (tests: every supported launch).
+// thresholds are lifted by set_wide_gemm_min_tiles(1) (tests: every supported launch).  Default 700 items (about three
+// per workgroup): inside a training step the mid-sized GEMMs (GPT-2's 288-384-tile qkv / fc launches) share the chip
+// with weight-gradient kernels on the side stream, and a persistent kernel with a static, equal share per CU waits
+// for its slowest CU - 84 us in the step against 46 us alone, 593k vs 598k tok/s end to end - so only launches with
+// several items per workgroup (the LM head: 616k vs 599k tok/s) come here.
 bool wide_gemm_eligible(const ConvArgs& a) {
     const int min_tiles = wide_gemm_min_tiles();
     if (min_tiles <= 0 || !wide_gemm_supported(a)) return false;
