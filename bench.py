@@ -52,6 +52,11 @@ def parse():
     p.add_argument("--no-sink", action="store_true")
     p.add_argument("--shard-optimizer", action="store_true", help="ZeRO stage 1: optimizer state sharded over the DP ranks")
     p.add_argument("--backend", default="auto")
+    p.add_argument("--breakdown", action="store_true",
+                   help="HIP-event phase timers: forward / backward / exposed communication / optimizer per step, added to the JSON")
+    p.add_argument("--comm", default=None, choices=["native", "c10d"], help="collective layer under RCCL (default: DPA_COMM or native)")
+    p.add_argument("--allreduce", default=None, choices=["ring", "direct"], help="native layer: RCCL's ring or the one-shot direct algorithm")
+    p.add_argument("--grad-wire", default=None, choices=["fp32", "bf16"], help="direct all-reduce: gradient format on the links")
     return p.parse_args()
 
 
@@ -77,8 +82,33 @@ def load_baseline(model: str, n: int, per_gpu_batch: int):
     return None
 
 
+def peak_flops(dtype: str) -> float:
+    """Dense MFMA peak of one MI355X (MI355X_MICROARCH.md): 2.5 PFLOP/s bf16; fp32 through the f32-input MFMA 157 TFLOP/s."""
+    return 2.5e15 if dtype == "bf16" else 157.3e12
+
+
+def load_baseline_own(model: str, per_gpu_batch: int):
+    """This framework's own recorded 1-GPU throughput (BASELINE_MEASURED.json, key "own"), for the efficiency field."""
+    path = os.path.join(ROOT, "BASELINE_MEASURED.json")
+    try:
+        with open(path) as f:
+            entry = json.load(f).get("own", {}).get(model)
+        if isinstance(entry, dict) and int(entry.get("batch", per_gpu_batch)) == per_gpu_batch:
+            return float(entry["1"])
+    except Exception:  # noqa: BLE001
+        return None
+    return None
+
+
 def main():
     args = parse()
+    # collective-layer choices must be in the environment before distributedpytorch_amd.comm is imported
+    if args.comm:
+        os.environ["DPA_COMM"] = args.comm
+    if args.allreduce:
+        os.environ["DPA_ALLREDUCE"] = args.allreduce
+    if args.grad_wire:
+        os.environ["DPA_GRAD_WIRE"] = args.grad_wire
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -129,6 +159,8 @@ def main():
             lr, momentum, wd, use_lp = 0.1, 0.9, 1e-4, True
             loss_fn = lambda: model.loss(x, y)  # noqa: E731
             items = batch
+            # training FLOPs per image = 3 x forward (forward, input gradients, weight gradients)
+            flops_item = 3.0 * resnet.flops_per_image(model, hw) if isinstance(model, resnet.ResNet) else None
             cfg = {"model": args.model, "global_batch": batch * world, "image": f"3x{hw}x{hw}"}
         elif args.model == "gpt2":
             from distributedpytorch_amd.models import gpt2
@@ -138,6 +170,7 @@ def main():
             lr, momentum, wd, use_lp = 0.01, 0.9, 0.0, True
             loss_fn = lambda: model.loss(x, y)  # noqa: E731
             items = batch * args.seq_len
+            flops_item = gpt2.flops_per_token(model.cfg, args.seq_len)
             unit = "tokens/sec"
             cfg = {"model": "gpt2-small-124M", "global_batch": batch * world, "seq_len": args.seq_len}
         else:  # mnist: the reference's own DP config (global batch 128, SGD lr .01 momentum .5)
@@ -148,6 +181,7 @@ def main():
             lr, momentum, wd, use_lp = 0.01, 0.5, 0.0, False
             loss_fn = lambda: mnist.nll_loss(model(x), y)  # noqa: E731
             items = batch
+            flops_item = 3.0 * 2.0 * 480500.0           # 480,500 MACs forward per sample, x3 for fwd + bwd
             cfg = {"model": "mnist_cnn", "global_batch": batch * world, "image": "1x28x28"}
 
         dp = DataParallel(model, communicator, bucket_mb=args.bucket_mb, first_bucket_mb=args.first_bucket_mb,
@@ -169,20 +203,31 @@ def main():
             graphed = GraphedStep(dp, lambda xx, yy: mnist.nll_loss(model(xx), yy), (x, y), after_backward=model._drop.advance)
             cfg["hipgraph"] = True
 
+        from distributedpytorch_amd.metrics import PhaseTimer
+        timer = PhaseTimer(device, enabled=args.breakdown)
+
         def step():
             if graphed is not None:
-                loss = graphed(x, y)
-                dp.reduce_all()
+                with timer.phase("forward+backward (hipGraph)"):
+                    loss = graphed(x, y)
+                with timer.phase("exposed_comm"):
+                    dp.reduce_all()
             else:
-                loss = loss_fn()
-                loss.backward()
-                dp.finish()
-            opt.step()
+                with timer.phase("forward"):
+                    loss = loss_fn()
+                with timer.phase("backward"):          # includes the bucket launches: communication overlapped with it
+                    loss.backward()
+                with timer.phase("exposed_comm"):      # what the compute stream still has to wait for after backward
+                    dp.finish()
+            with timer.phase("optimizer"):
+                opt.step()
             return loss
 
         from distributedpytorch_amd.utils.gcguard import GCGuard
         for _ in range(args.warmup):
             step()
+        timer.summary()                      # drop the warm-up's samples
+        dp.stats["allreduce_calls"] = dp.stats["allreduce_bytes"] = 0
         # the collector runs at a fixed step period, the same step on every rank (as in train.py): a generation-2
         # pause on one rank is a pause of the whole synchronous job
         with GCGuard(period=500) as guard:
@@ -196,9 +241,16 @@ def main():
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
         elapsed = communicator.all_reduce_scalar(elapsed, "max")
+        layer = "native (csrc/rccl_comm.cpp)" if communicator.native is not None else \
+            ("c10d" if torch.distributed.is_initialized() else "none (single process, no collectives)")
         result = {"elapsed": elapsed, "items_per_rank_step": items, "loss": float(loss.detach().float().cpu()),
+                  "flops_per_item": flops_item,
+                  "allreduce_bytes_per_step": dp.stats["allreduce_bytes"] // max(1, args.steps),
+                  "allreduce_calls_per_step": dp.stats["allreduce_calls"] / max(1, args.steps),
+                  "breakdown_ms": ({k: round(v, 3) for k, v in timer.summary().items()} if args.breakdown else None),
                   "config": dict(cfg, parallelism=f"dp{world}", per_gpu_batch=batch,
-                                 buckets=len(dp.buckets), optimizer=f"fused SGD momentum {momentum}")}
+                                 buckets=len(dp.buckets), optimizer=f"fused SGD momentum {momentum}", comm_layer=layer,
+                                 allreduce=("direct/" + communicator.grad_wire) if (communicator.native is not None and communicator._direct) else "ring")}
 
     if rank == 0:
         elapsed = result["elapsed"]
@@ -215,6 +267,18 @@ def main():
             "data": "synthetic (random-init weights, on-device random inputs of the named shape)",
             "final_loss": result["loss"], "config": result["config"],
         }
+        dtype = out["dtype"]
+        if result.get("flops_per_item"):
+            # model FLOP utilisation against the dense MFMA peak of the GPUs used (no sparsity figures)
+            out["mfu"] = round(value * result["flops_per_item"] / (world * peak_flops(dtype)), 4)
+        base1 = load_baseline_own(args.model, pgb)
+        if base1 and not (args.pipeline and args.pipeline > 1):
+            # weak-scaling efficiency against this framework's own recorded 1-GPU number (BASELINE_MEASURED.json "own")
+            from distributedpytorch_amd.metrics import scaling_efficiency
+            out["scaling_efficiency_vs_recorded_1gpu"] = round(scaling_efficiency(value, base1, world), 4)
+        for k in ("allreduce_bytes_per_step", "allreduce_calls_per_step", "breakdown_ms"):
+            if result.get(k) is not None:
+                out[k] = result[k]
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
         communicator.barrier()

@@ -125,8 +125,7 @@ def save_checkpoint(path: str, module: nn.Module, optimizer=None, epoch: int = 0
         if pipeline_comm.rank == 0:
             merged: "OrderedDict[str, torch.Tensor]" = OrderedDict()
             for shard, _ in shards:
-                for k, v in shard.items():
-                    merged[_strip_stage_prefix(k)] = v
+                merged.update(shard)      # export_state_dict already names every entry by its model-level key
             sd = merged
             opt_sd = [o for _, o in shards]
         else:
@@ -146,14 +145,10 @@ def save_checkpoint(path: str, module: nn.Module, optimizer=None, epoch: int = 0
     return path
 
 
-def _strip_stage_prefix(key: str) -> str:
-    """``nn.Sequential`` stage wrappers name entries ``0.conv1.weight``; a single-module
-    stage (the reference's Net1 / Net2) is exported under its own attribute names."""
-    return key
-
-
-def load_checkpoint(path: str, module: nn.Module, optimizer=None, strict: bool = True, flat=None) -> dict:
-    """Resume: loads model (and optimizer) state; refreshes the bf16 shadows."""
+def load_checkpoint(path: str, module: nn.Module, optimizer=None, strict: bool = True, flat=None,
+                    stage: Optional[int] = None) -> dict:
+    """Resume: loads model (and optimizer) state; refreshes the bf16 shadows.  ``stage``: this rank's pipeline
+    stage - a pipeline checkpoint stores one optimizer state per stage (a list), each stage takes its own back."""
     payload = torch.load(path, map_location="cpu", weights_only=True)
     sd = payload["model"] if isinstance(payload, dict) and "model" in payload else payload
     key_map = getattr(module, "_dpa_key_map", None)
@@ -162,6 +157,8 @@ def load_checkpoint(path: str, module: nn.Module, optimizer=None, strict: bool =
     import_state_dict(module, sd_use, strict=strict)
     if optimizer is not None and isinstance(payload, dict) and payload.get("optimizer") is not None:
         o = payload["optimizer"]
+        if isinstance(o, (list, tuple)):
+            o = o[stage] if (stage is not None and 0 <= stage < len(o)) else None
         if isinstance(o, dict):
             optimizer.load_state_dict(o)
     if flat is not None:

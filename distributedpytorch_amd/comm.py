@@ -28,6 +28,12 @@ _SYNC_DEBUG = os.environ.get("DPA_SYNC_DEBUG", "0") == "1"
 # DPA_FORCE_COLLECTIVES=1: issue the real collective even at world size 1 (tests: the whole RCCL call path on one GPU)
 _FORCE_COLLECTIVES = os.environ.get("DPA_FORCE_COLLECTIVES", "0") == "1"
 _GLOO_NATIVE_DEVICE = os.environ.get("DPA_GLOO_DEVICE", "staged").lower() == "native"
+# Which layer carries device collectives under the RCCL backend: "native" = csrc/rccl_comm.cpp (own C++ communicator,
+# own comm stream, ncclCommSplit sub-groups, optional direct / bf16-wire all-reduce; the default), "c10d" =
+# torch.distributed's ProcessGroupNCCL.  The native layer is checked by a self-test at start-up (a small and a
+# bucket-sized all-reduce with a host watchdog, result verified); if any rank fails it, EVERY rank falls back to c10d.
+_COMM_LAYER = os.environ.get("DPA_COMM", "native").lower()
+_SELFTEST_TIMEOUT_S = float(os.environ.get("DPA_COMM_SELFTEST_TIMEOUT", "60"))
 
 
 def set_sync_debug(flag: bool) -> None:
@@ -94,8 +100,31 @@ def init_process_group(backend: str = "auto", init_method: Optional[str] = None,
     if not dist.is_initialized():
         dist.init_process_group(**kwargs)
     comm = Communicator(group=None, device=device)
-    if os.environ.get("DPA_COMM", "c10d").lower() == "native" and be == "nccl" and device is not None and device.type == "cuda":
+    if _COMM_LAYER == "native" and be == "nccl" and device is not None and device.type == "cuda" and \
+            (comm.world_size > 1 or _FORCE_COLLECTIVES):
         comm.attach_native()
+    return comm
+
+
+def init_native_group(init_method: str, rank: int, world_size: int, device: torch.device,
+                      timeout_s: float = 300.0) -> "Communicator":
+    """Rendezvous WITHOUT torch.distributed: rank 0 serves a small TCP key-value store at ``tcp://host:port``
+    (distributedpytorch_amd/store.py), the 128-byte RCCL unique id travels through it, and every collective of the
+    returned communicator runs on the native RCCL layer (csrc/rccl_comm.cpp).  Same contract as the reference's
+    ``dist.init_process_group(init_method="tcp://...")`` (DP.py:161, MP.py:177)."""
+    from .ops import _ext
+    from .store import TCPKVStore, parse_tcp_url
+    rccl_env_defaults()
+    host, port = parse_tcp_url(init_method)
+    store = TCPKVStore(host, port, is_master=(rank == 0), timeout_s=timeout_s)
+    C = _ext.load()
+    if rank == 0:
+        store.set("rccl/unique_id/world", C.RcclComm.unique_id())
+    uid = store.get("rccl/unique_id/world", timeout_s)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    comm = Communicator(group=None, device=device, ranks=None, static=(rank, world_size), store=store)
+    comm.native = C.RcclComm(uid, rank, world_size, index)
+    comm._selftest_native(strict=True)
     return comm
 
 
@@ -115,16 +144,15 @@ def get_world_size() -> int:
 class _NativeWork:
     """Handle of an operation on the native RCCL communicator's stream (csrc/rccl_comm.cpp)."""
 
-    def __init__(self, native, ticket: int, keep=()):
-        self._native, self._ticket, self._keep = native, ticket, keep
+    def __init__(self, native, ticket: int):
+        self._native, self._ticket = native, ticket    # the buffers are recorded on the comm stream by the C++ side
 
     def wait(self):
         self._native.wait(self._ticket)      # the current compute stream waits on the event; no host block
-        self._keep = ()
         return True
 
     def is_completed(self):
-        return False
+        return bool(self._native.query(self._ticket))
 
 
 class _DoneWork:
@@ -161,57 +189,131 @@ class Communicator:
     buffers and nothing is staged through the host.
     """
 
-    def __init__(self, group=None, device: Optional[torch.device] = None, ranks: Optional[Sequence[int]] = None):
+    def __init__(self, group=None, device: Optional[torch.device] = None, ranks: Optional[Sequence[int]] = None,
+                 static: Optional[tuple] = None, store=None):
         self.group = group
         self.device = device
         self._ranks = list(ranks) if ranks is not None else None
-        self.initialized = dist.is_initialized()
-        self.native = None                    # optional csrc/rccl_comm.cpp communicator over the same ranks
+        self._static = static                 # (rank, world_size) of a communicator that lives without c10d
+        self.store = store                    # store.TCPKVStore of such a communicator (objects, bootstrap)
+        self.initialized = dist.is_initialized() and static is None
+        self.native = None                    # csrc/rccl_comm.cpp communicator over the same ranks
+        # all-reduce algorithm of the native layer: "ring" = RCCL's own ncclAllReduce, "direct" = one-shot
+        # reduce-scatter + all-gather over the 7 xGMI links (rccl_comm.cpp); wire format of the direct form
         self._direct = os.environ.get("DPA_ALLREDUCE", "ring").lower() == "direct"
+        self.grad_wire = os.environ.get("DPA_GRAD_WIRE", "fp32").lower()
         self._scratch = {}
+        self._obj_seq = 0
 
-    # ---- native RCCL communicator (DPA_COMM=native): own comm stream, hipEvent hand-offs, direct all-reduce ----
-    def attach_native(self) -> None:
-        """Collective over this communicator's ranks: bootstrap a native ``RcclComm`` (the 128-byte unique id
-        travels through the existing process group) and route device all-reduces through it."""
+    # ---- native RCCL communicator: own comm stream, event hand-offs, direct / bf16-wire all-reduce ----
+    def attach_native(self, parent: Optional["Communicator"] = None, member: bool = True) -> None:
+        """Collective over this communicator's ranks (over the PARENT's ranks when ``parent`` is given: every rank
+        of the parent calls it, members and non-members alike - ncclCommSplit is collective over the parent).
+
+        World communicator: bootstrap a native ``RcclComm`` (the 128-byte unique id travels through the existing
+        process group).  Sub-communicator: ``ncclCommSplit`` of the parent's native communicator."""
         from .ops import _ext
         C = _ext.load()
         if self.device is None or self.device.type != "cuda":
             raise RuntimeError("the native RCCL communicator needs a GPU device")
+        if parent is not None:
+            if parent.native is None:
+                return
+            color = self._ranks[0] if member else -1             # one colour per sub-group: its first global rank
+            self.native = parent.native.split(color, self.rank if member else 0, self.rank if member else 0,
+                                              self.world_size if member else 1)
+            return
         box = [C.RcclComm.unique_id() if self.rank == 0 else None]
         if self.world_size > 1:
             dist.broadcast_object_list(box, src=self.to_global(0), group=self.group)
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.native = C.RcclComm(box[0], self.rank, self.world_size, index)
+        self._selftest_native(strict=False)
+
+    def _selftest_native(self, strict: bool) -> None:
+        """First contact of the native layer with the machine: a 4 KB and a 32 MB all-reduce of known values under a
+        host watchdog.  ``strict``: raise on failure (no c10d to fall back to); else every rank drops to c10d when
+        ANY rank failed (decided by a c10d all-reduce, so the ranks cannot disagree)."""
+        import time
+        ok, why = True, ""
+        try:
+            for n in (1024, 8 * 2 ** 20):
+                t = torch.full((n,), float(self.rank + 1), dtype=torch.float32, device=self.device)
+                ticket = self.native.all_reduce(t, 0)
+                t0 = time.monotonic()
+                while not self.native.query(ticket):
+                    if time.monotonic() - t0 > _SELFTEST_TIMEOUT_S:
+                        raise TimeoutError(f"native all-reduce of {n} floats did not complete in {_SELFTEST_TIMEOUT_S:.0f} s")
+                    time.sleep(0.0005)
+                self.native.wait(ticket)
+                want = self.world_size * (self.world_size + 1) / 2.0
+                got = t[:: max(1, n // 64)].float().cpu()
+                if not bool((got == want).all()):
+                    raise RuntimeError(f"native all-reduce returned {float(got[0])}, expected {want}")
+        except Exception as e:  # noqa: BLE001
+            ok, why = False, f"{type(e).__name__}: {e}"
+        if strict:
+            if not ok:
+                raise RuntimeError(f"native RCCL communicator failed its self-test: {why}")
+            return
+        all_ok = ok
+        if self.world_size > 1:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            all_ok = bool(int(flag.item()) == 1)
+        if not all_ok:
+            import sys
+            print(f"[comm] rank {self.global_rank}: native RCCL layer failed its self-test"
+                  f"{' here (' + why + ')' if not ok else ' on another rank'}; falling back to c10d", file=sys.stderr, flush=True)
+            try:
+                self.native.abort()
+            except Exception:  # noqa: BLE001
+                pass
+            self.native = None
+
+    def _on_native(self, *tensors: torch.Tensor) -> bool:
+        return self.native is not None and all(t.is_cuda and t.is_contiguous() for t in tensors)
 
     def _native_all_reduce(self, tensor: torch.Tensor, op):
         code = {dist.ReduceOp.SUM: 0, dist.ReduceOp.MAX: 1, dist.ReduceOp.MIN: 2}.get(op)
-        if code is None or not tensor.is_cuda or not tensor.is_contiguous():
+        if code is None or not self._on_native(tensor):
             return None
         if self._direct and code == 0 and tensor.dtype == torch.float32 and self.world_size > 1:
-            shard = -(-tensor.numel() // self.world_size)
-            need = shard * (self.world_size - 1)
-            scratch = self._scratch.get(need)
+            # one-shot reduce-scatter + all-gather over the direct links; scratch per message size, reused
+            bf16 = self.grad_wire == "bf16"
+            shard = (-(-tensor.numel() // self.world_size) + 7) // 8 * 8
+            need = shard * ((2 * self.world_size - 1) if bf16 else (self.world_size - 1))
+            key = (need, bf16)
+            scratch = self._scratch.get(key)
             if scratch is None:
-                scratch = self._scratch[need] = torch.empty(need, dtype=torch.float32, device=tensor.device)
-            return _NativeWork(self.native, self.native.all_reduce_direct(tensor, scratch), (tensor,))
-        return _NativeWork(self.native, self.native.all_reduce(tensor, code), (tensor,))
+                scratch = self._scratch[key] = torch.empty(need, dtype=torch.bfloat16 if bf16 else torch.float32,
+                                                           device=tensor.device)
+            return _NativeWork(self.native, self.native.all_reduce_direct(tensor, scratch))
+        return _NativeWork(self.native, self.native.all_reduce(tensor, code))
 
     # ---- queries (reference: dist.get_rank / get_world_size, DP.py:108,112) ----
     @property
     def rank(self) -> int:
+        if self._static is not None:
+            return self._static[0]
         return dist.get_rank(self.group) if self.initialized else 0
 
     @property
     def world_size(self) -> int:
+        if self._static is not None:
+            return self._static[1]
         return dist.get_world_size(self.group) if self.initialized else 1
 
     @property
     def global_rank(self) -> int:
+        if self._static is not None:
+            return self._ranks[self._static[0]] if self._ranks is not None else self._static[0]
         return dist.get_rank() if self.initialized else 0
 
     @property
     def backend(self) -> str:
+        if self._static is not None:
+            return "nccl"
         return dist.get_backend(self.group) if self.initialized else "none"
 
     def to_global(self, group_rank: int) -> int:
@@ -220,7 +322,27 @@ class Communicator:
         return self._ranks[group_rank]
 
     # ---- collectives ----
+    def _native_result(self, ticket: int, async_op: bool):
+        work = _NativeWork(self.native, ticket)
+        if _SYNC_DEBUG:
+            self.native.synchronize()
+        if async_op:
+            return work
+        work.wait()
+        return None
+
+    def _need_c10d(self, what: str) -> None:
+        if self._static is not None:
+            raise RuntimeError(f"{what}: this communicator was built without torch.distributed (init_native_group) "
+                               f"and only moves contiguous device tensors")
+
+    def _single(self) -> bool:
+        """World size 1 with nothing forcing the real call path."""
+        return self.world_size == 1 and not (_FORCE_COLLECTIVES and (self.native is not None or dist.is_initialized()))
+
     def all_reduce(self, tensor: torch.Tensor, op=dist.ReduceOp.SUM, async_op: bool = False):
+        if self._single():
+            return _DoneWork() if async_op else None
         if self.native is not None:
             work = self._native_all_reduce(tensor, op)
             if work is not None:
@@ -230,8 +352,7 @@ class Communicator:
                     return work
                 work.wait()
                 return None
-        if self.world_size == 1 and not (_FORCE_COLLECTIVES and dist.is_initialized()):
-            return _DoneWork() if async_op else None
+        self._need_c10d("all_reduce")
         if self._staged(tensor) and not _GLOO_NATIVE_DEVICE:
             host = tensor.cpu()
             work = _StagedWork(dist.all_reduce(host, op=op, group=self.group, async_op=True), host, tensor)
@@ -254,6 +375,9 @@ class Communicator:
         The sharded optimizer's gradient path (parallel/dp.py, ``shard_optimizer``)."""
         if self.world_size == 1:
             return _DoneWork() if async_op else None
+        if self._on_native(tensor):
+            return self._native_result(self.native.reduce(tensor, dst), async_op)
+        self._need_c10d("reduce")
         if self._staged(tensor) and not _GLOO_NATIVE_DEVICE:
             host = tensor.cpu()
             inner = dist.reduce(host, dst=self.to_global(dst), group=self.group, async_op=True)
@@ -269,6 +393,9 @@ class Communicator:
         if self.world_size == 1:
             output.copy_(input)
             return _DoneWork() if async_op else None
+        if self._on_native(output, input):
+            return self._native_result(self.native.reduce_scatter(output, input), async_op)
+        self._need_c10d("reduce_scatter")
         work = dist.reduce_scatter_tensor(output, input, group=self.group, async_op=True)
         if async_op and not _SYNC_DEBUG:
             return work
@@ -279,6 +406,9 @@ class Communicator:
         if self.world_size == 1:
             output.copy_(input)
             return _DoneWork() if async_op else None
+        if self._on_native(output, input):
+            return self._native_result(self.native.all_gather(output, input), async_op)
+        self._need_c10d("all_gather")
         work = dist.all_gather_into_tensor(output, input, group=self.group, async_op=True)
         if async_op and not _SYNC_DEBUG:
             return work
@@ -288,6 +418,9 @@ class Communicator:
     def broadcast(self, tensor: torch.Tensor, src: int = 0, async_op: bool = False):
         if self.world_size == 1:
             return _DoneWork() if async_op else None
+        if self._on_native(tensor):
+            return self._native_result(self.native.broadcast(tensor, src), async_op)
+        self._need_c10d("broadcast")
         if self._staged(tensor) and not _GLOO_NATIVE_DEVICE:
             host = tensor.cpu()
             work = _StagedWork(dist.broadcast(host, src=self.to_global(src), group=self.group, async_op=True), host, tensor)
@@ -302,11 +435,17 @@ class Communicator:
         return _DoneWork() if async_op else None
 
     def barrier(self):
-        if self.world_size > 1:
-            if self.backend == "nccl" and self.device is not None:
-                dist.barrier(group=self.group, device_ids=[self.device.index])
-            else:
-                dist.barrier(group=self.group)
+        if self.world_size <= 1:
+            return
+        if self._static is not None:         # no c10d: a one-element all-reduce and a host wait for it
+            t = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self.native.wait(self.native.all_reduce(t, 0))
+            torch.cuda.current_stream(self.device).synchronize()
+            return
+        if self.backend == "nccl" and self.device is not None:
+            dist.barrier(group=self.group, device_ids=[self.device.index])
+        else:
+            dist.barrier(group=self.group)
 
     # ---- point to point (reference: MP.py:140,144,153,167) ----
     def _staged(self, tensor: torch.Tensor) -> bool:
@@ -318,6 +457,10 @@ class Communicator:
         return tensor.is_cuda and self.backend != "nccl"
 
     def send(self, tensor: torch.Tensor, dst: int):
+        if self._on_native(tensor):
+            self._native_result(self.native.batch_p2p([(True, tensor, dst)]), False)
+            return
+        self._need_c10d("send")
         if self._staged(tensor):
             dist.send(tensor.cpu(), dst=self.to_global(dst), group=self.group)
             return
@@ -326,6 +469,10 @@ class Communicator:
             torch.cuda.synchronize(tensor.device)
 
     def recv(self, tensor: torch.Tensor, src: int):
+        if self._on_native(tensor):
+            self._native_result(self.native.batch_p2p([(False, tensor, src)]), False)
+            return
+        self._need_c10d("recv")
         if self._staged(tensor):
             host = torch.empty(tensor.shape, dtype=tensor.dtype)
             dist.recv(host, src=self.to_global(src), group=self.group)
@@ -336,12 +483,18 @@ class Communicator:
             torch.cuda.synchronize(tensor.device)
 
     def isend(self, tensor: torch.Tensor, dst: int):
+        if self._on_native(tensor):
+            return self._native_result(self.native.batch_p2p([(True, tensor, dst)]), True)
+        self._need_c10d("isend")
         if self._staged(tensor):
             host = tensor.cpu()
             return _StagedWork(dist.isend(host, dst=self.to_global(dst), group=self.group), host, None)
         return dist.isend(tensor, dst=self.to_global(dst), group=self.group)
 
     def irecv(self, tensor: torch.Tensor, src: int):
+        if self._on_native(tensor):
+            return self._native_result(self.native.batch_p2p([(False, tensor, src)]), True)
+        self._need_c10d("irecv")
         if self._staged(tensor):
             host = torch.empty(tensor.shape, dtype=tensor.dtype)
             return _StagedWork(dist.irecv(host, src=self.to_global(src), group=self.group), host, tensor)
@@ -349,9 +502,14 @@ class Communicator:
 
     def batch_p2p(self, ops: List[tuple]):
         """``ops`` = [("send"|"recv", tensor, peer), ...] issued as one grouped RCCL
-        call (ncclGroupStart/End) so a send and a recv to neighbours cannot deadlock."""
+        call (ncclGroupStart/End) so a send and a recv to neighbours cannot deadlock.  Returns a list of handles
+        (one per op; on the native layer they all stand for the one grouped call)."""
         if not ops:
             return []
+        if self._on_native(*[t for _, t, _ in ops]):
+            work = self._native_result(self.native.batch_p2p([(kind == "send", t, peer) for kind, t, peer in ops]), True)
+            return [work] * len(ops)
+        self._need_c10d("batch_p2p")
         if any(self._staged(t) for _, t, _ in ops):       # gloo: non-blocking host transfers, one handle per op
             return [self.isend(t, peer) if kind == "send" else self.irecv(t, peer) for kind, t, peer in ops]
         p2p = []
@@ -365,9 +523,20 @@ class Communicator:
         return works
 
     # ---- object helpers (cold path: checkpoint merge, metrics) ----
+    def _obj_key(self, what: str) -> str:
+        self._obj_seq += 1                    # every rank of the communicator calls the object helpers in the same order
+        name = "world" if self._ranks is None else "g" + "_".join(map(str, self._ranks))
+        return f"obj/{name}/{what}/{self._obj_seq}"
+
     def gather_object(self, obj, dst: int = 0):
         if self.world_size == 1:
             return [obj]
+        if self._static is not None:
+            key = self._obj_key("gather")
+            self.store.set_object(f"{key}/{self.rank}", obj)
+            if self.rank != dst:
+                return None
+            return [self.store.get_object(f"{key}/{r}") for r in range(self.world_size)]
         out = [None] * self.world_size if self.rank == dst else None
         dist.gather_object(obj, out, dst=self.to_global(dst), group=self.group)
         return out
@@ -375,6 +544,12 @@ class Communicator:
     def broadcast_object(self, obj, src: int = 0):
         if self.world_size == 1:
             return obj
+        if self._static is not None:
+            key = self._obj_key("bcast")
+            if self.rank == src:
+                self.store.set_object(key, obj)
+                return obj
+            return self.store.get_object(key)
         box = [obj]
         dist.broadcast_object_list(box, src=self.to_global(src), group=self.group)
         return box[0]
@@ -382,25 +557,46 @@ class Communicator:
     def all_reduce_scalar(self, value: float, op: str = "sum") -> float:
         if self.world_size == 1:
             return float(value)
+        rop = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op]
+        if self._static is not None:
+            t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
+            self.all_reduce(t, op=rop)
+            return float(t.item())
         dev = self.device if (self.device is not None and self.backend == "nccl") else torch.device("cpu")
         t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
-        rop = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op]
         dist.all_reduce(t, op=rop, group=self.group)
         return float(t.item())
 
     # ---- sub-groups ----
     def split(self, ranks: Sequence[int]) -> Optional["Communicator"]:
-        """Collective over the *world*: every rank must call ``split`` with the same
+        """Collective over THIS communicator (the world): every rank must call ``split`` with the same
         sequence of rank lists, in the same order.  Returns the communicator when
-        this rank is a member, else None."""
+        this rank is a member, else None.  On the native layer the sub-communicator is an ``ncclCommSplit`` of this
+        one (members pass one colour, the others NCCL_SPLIT_NOCOLOR)."""
         ranks = list(ranks)
+        member = self.global_rank in ranks
+        if self._static is not None:
+            sub = Communicator(group=None, device=self.device, ranks=ranks,
+                               static=(ranks.index(self.global_rank) if member else 0, len(ranks)), store=self.store)
+            sub.attach_native(parent=self, member=member)
+            return sub if member else None
         group = dist.new_group(ranks=ranks)
-        if dist.get_rank() in ranks:
-            sub = Communicator(group=group, device=self.device, ranks=ranks)
-            if self.native is not None:
-                sub.attach_native()
-            return sub
-        return None
+        sub = Communicator(group=group, device=self.device, ranks=ranks) if member else None
+        if self.native is not None:
+            if member:
+                sub.attach_native(parent=self, member=True)
+            else:                                            # ncclCommSplit is collective over the parent
+                Communicator(group=None, device=self.device, ranks=ranks, static=(0, 1)).attach_native(parent=self, member=False)
+        return sub
+
+    def close(self) -> None:
+        """Release the native communicator and the rendezvous store of a c10d-free communicator."""
+        if self.native is not None:
+            self.native.synchronize()
+            self.native = None
+        if self.store is not None and self._ranks is None:
+            self.store.close()
+            self.store = None
 
 
 def build_grid(world: Communicator, dp: int, pp: int):
@@ -409,7 +605,8 @@ def build_grid(world: Communicator, dp: int, pp: int):
     ``(pp_comm, dp_comm, replica, stage)``; ``pp_comm`` spans the stages of this
     replica, ``dp_comm`` spans the replicas of this stage.  Ranks beyond ``dp * pp``
     (idle, like ranks >= 2 in the reference's MP script) get ``(None, None, -1, -1)``.
-    Collective over the world: EVERY rank must call it (group creation is global)."""
+    Collective over the world: EVERY rank must call it (group creation is global).  When ranks idle, ``world.active``
+    is set to a communicator of the working ranks (what end-of-run barriers must use: an idle rank has left by then)."""
     n = world.world_size
     if dp * pp > n:
         raise ValueError(f"dp({dp}) x pp({pp}) > world size {n}")
@@ -419,6 +616,7 @@ def build_grid(world: Communicator, dp: int, pp: int):
     active = me < dp * pp
     replica, stage = divmod(me, pp) if active else (-1, -1)
     pp_comm = dp_comm = None
+    world.active = world.split(list(range(dp * pp))) if dp * pp < n else None
     for r in range(dp):
         c = world.split([r * pp + s for s in range(pp)])
         if r == replica:

@@ -613,7 +613,8 @@ Tensor softmax_ce_bwd(const Tensor& logits, const Tensor& targets, const Tensor&
 // ---------------------------------------------------------------- optimizer / casts
 void sgd_momentum(Tensor& p, Tensor& grad, const c10::optional<Tensor>& m, const c10::optional<Tensor>& p_lp, double lr,
                   double mu, double wd, double grad_scale, bool zero_grad, bool nesterov,
-                  const c10::optional<Tensor>& seg_ends, const c10::optional<Tensor>& seg_wd) {
+                  const c10::optional<Tensor>& seg_ends, const c10::optional<Tensor>& seg_wd,
+                  const c10::optional<Tensor>& scale_dev) {
     CHECK_F32(p); CHECK_F32(grad);
     const int64_t n = p.numel();
     TORCH_CHECK(grad.numel() == n, "sgd: grad size");
@@ -636,13 +637,15 @@ void sgd_momentum(Tensor& p, Tensor& grad, const c10::optional<Tensor>& m, const
         TORCH_CHECK(seg_wd->numel() == nseg && nseg >= 1, "sgd: segment table");
         se = (const long*)seg_ends->data_ptr<int64_t>(); sw = seg_wd->data_ptr<float>();
     }
+    const float* sd = nullptr;
+    if (scale_dev.has_value() && scale_dev->defined()) { CHECK_F32((*scale_dev)); TORCH_CHECK(scale_dev->numel() == 1, "sgd: scale_dev is one float"); sd = scale_dev->data_ptr<float>(); }
     Guard g(p);
     dpa::sgd_momentum(p.data_ptr<float>(), grad.data_ptr<float>(), mp, lp, n, (float)lr, (float)mu, (float)wd,
-                      (float)grad_scale, zero_grad, nesterov, se, sw, nseg, cur_stream());
+                      (float)grad_scale, zero_grad, nesterov, se, sw, nseg, sd, cur_stream());
 }
 
 void adamw(Tensor& p, Tensor& grad, Tensor& m, Tensor& v, const c10::optional<Tensor>& p_lp, double lr, double b1, double b2,
-           double eps, double wd, double grad_scale, int64_t step, bool zero_grad) {
+           double eps, double wd, double grad_scale, int64_t step, bool zero_grad, const c10::optional<Tensor>& scale_dev) {
     CHECK_F32(p); CHECK_F32(grad); CHECK_F32(m); CHECK_F32(v);
     const int64_t n = p.numel();
     TORCH_CHECK(grad.numel() == n && m.numel() == n && v.numel() == n, "adamw: sizes");
@@ -652,10 +655,12 @@ void adamw(Tensor& p, Tensor& grad, Tensor& m, Tensor& v, const c10::optional<Te
         TORCH_CHECK(p_lp->scalar_type() == at::kBFloat16 && p_lp->numel() == n, "adamw: bf16 shadow");
         lp = p_lp->data_ptr();
     }
+    const float* sd = nullptr;
+    if (scale_dev.has_value() && scale_dev->defined()) { CHECK_F32((*scale_dev)); TORCH_CHECK(scale_dev->numel() == 1, "adamw: scale_dev is one float"); sd = scale_dev->data_ptr<float>(); }
     Guard g(p);
     const double bc1 = 1.0 - std::pow(b1, (double)step), bc2 = 1.0 - std::pow(b2, (double)step);
     dpa::adamw(p.data_ptr<float>(), grad.data_ptr<float>(), m.data_ptr<float>(), v.data_ptr<float>(), lp, n, (float)lr,
-               (float)b1, (float)b2, (float)eps, (float)wd, (float)grad_scale, (float)bc1, (float)bc2, zero_grad, cur_stream());
+               (float)b1, (float)b2, (float)eps, (float)wd, (float)grad_scale, (float)bc1, (float)bc2, zero_grad, sd, cur_stream());
 }
 
 void cast_f32_to_bf16(const Tensor& x, Tensor& y) {
@@ -820,8 +825,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("ew2", &ew2);
     m.def("softmax_ce_fwd", &softmax_ce_fwd);
     m.def("softmax_ce_bwd", &softmax_ce_bwd);
-    m.def("sgd_momentum", &sgd_momentum);
-    m.def("adamw", &adamw);
+    m.def("sgd_momentum", &sgd_momentum, py::arg("p"), py::arg("grad"), py::arg("m"), py::arg("p_lp"), py::arg("lr"), py::arg("mu"),
+          py::arg("wd"), py::arg("grad_scale"), py::arg("zero_grad"), py::arg("nesterov"), py::arg("seg_ends"), py::arg("seg_wd"),
+          py::arg("scale_dev") = py::none());
+    m.def("adamw", &adamw, py::arg("p"), py::arg("grad"), py::arg("m"), py::arg("v"), py::arg("p_lp"), py::arg("lr"), py::arg("b1"), py::arg("b2"),
+          py::arg("eps"), py::arg("wd"), py::arg("grad_scale"), py::arg("step"), py::arg("zero_grad"), py::arg("scale_dev") = py::none());
     m.def("cast_f32_to_bf16", &cast_f32_to_bf16);
     m.def("cast_bf16_to_f32", &cast_bf16_to_f32);
     m.def("conv5_pool_relu_fwd", &conv5_pool_relu_fwd);

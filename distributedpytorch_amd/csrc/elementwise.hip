@@ -205,8 +205,12 @@ void launch_ew(const void* a, const void* b, void* y, long n, hipStream_t st) {
 template <bool LP>
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                   unsigned short* __restrict__ plp, long n4, long n, float lr, float mu,
-                                                  float wd_all, float gs, int zero_grad, int nesterov,
-                                                  const long* __restrict__ seg_ends, const float* __restrict__ seg_wd, int nseg) {
+                                                  float wd_all, float gs_host, int zero_grad, int nesterov,
+                                                  const long* __restrict__ seg_ends, const float* __restrict__ seg_wd, int nseg,
+                                                  const float* __restrict__ gs_dev) {
+    // gs_dev: optional device scalar multiplied into the gradient scale (the clip coefficient of clip_grad_norm:
+    // clipping costs no pass of its own over the gradient buffer)
+    const float gs = gs_dev != nullptr ? gs_host * gs_dev[0] : gs_host;
     GRID_STRIDE(i, n4) {
         // per-segment weight decay (conv / linear weights decay, norm affine + biases do not): binary
         // search the segment table; segments are 64-element aligned so a float4 never straddles one
@@ -253,8 +257,9 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
 template <bool LP>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, unsigned short* __restrict__ plp, long n,
-                                                    float lr, float b1, float b2, float eps, float wd, float gs,
-                                                    float bc1, float bc2, int zero_grad) {
+                                                    float lr, float b1, float b2, float eps, float wd, float gs_host,
+                                                    float bc1, float bc2, int zero_grad, const float* __restrict__ gs_dev) {
+    const float gs = gs_dev != nullptr ? gs_host * gs_dev[0] : gs_host;
     GRID_STRIDE(i, n) {
         const float gg = g[i] * gs;
         const float mm = b1 * m[i] + (1.f - b1) * gg;
@@ -336,25 +341,25 @@ void gelu_bwd(const void* dy, const void* x, void* dx, long n, hipStream_t st) {
 
 void sgd_momentum(float* p, float* g, float* m, void* p_lp, long n, float lr, float mu, float wd,
                   float grad_scale, int zero_grad, int nesterov, const long* seg_ends, const float* seg_wd, int nseg,
-                  hipStream_t st) {
+                  const float* grad_scale_dev, hipStream_t st) {
     const long n4 = n / 4;
     dim3 grid(grid_for(n4)), block(256);
     if (p_lp)
         hipLaunchKernelGGL((sgd_kernel<true>), grid, block, 0, st, p, g, m, (unsigned short*)p_lp, n4, n, lr, mu, wd,
-                           grad_scale, zero_grad, nesterov, seg_ends, seg_wd, nseg);
+                           grad_scale, zero_grad, nesterov, seg_ends, seg_wd, nseg, grad_scale_dev);
     else
         hipLaunchKernelGGL((sgd_kernel<false>), grid, block, 0, st, p, g, m, (unsigned short*)nullptr, n4, n, lr, mu, wd,
-                           grad_scale, zero_grad, nesterov, seg_ends, seg_wd, nseg);
+                           grad_scale, zero_grad, nesterov, seg_ends, seg_wd, nseg, grad_scale_dev);
 }
 void adamw(float* p, float* g, float* m, float* v, void* p_lp, long n, float lr, float b1, float b2, float eps,
-           float wd, float grad_scale, float bc1, float bc2, int zero_grad, hipStream_t st) {
+           float wd, float grad_scale, float bc1, float bc2, int zero_grad, const float* grad_scale_dev, hipStream_t st) {
     dim3 grid(grid_for(n)), block(256);
     if (p_lp)
         hipLaunchKernelGGL((adamw_kernel<true>), grid, block, 0, st, p, g, m, v, (unsigned short*)p_lp, n, lr, b1, b2, eps,
-                           wd, grad_scale, bc1, bc2, zero_grad);
+                           wd, grad_scale, bc1, bc2, zero_grad, grad_scale_dev);
     else
         hipLaunchKernelGGL((adamw_kernel<false>), grid, block, 0, st, p, g, m, v, (unsigned short*)nullptr, n, lr, b1, b2,
-                           eps, wd, grad_scale, bc1, bc2, zero_grad);
+                           eps, wd, grad_scale, bc1, bc2, zero_grad, grad_scale_dev);
 }
 void cast_f32_to_bf16(const float* x, void* y, long n, hipStream_t st) {
     hipLaunchKernelGGL(cast_f2b_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, (unsigned short*)y, n);

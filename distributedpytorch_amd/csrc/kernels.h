@@ -146,9 +146,10 @@ void softmax_ce_bwd(const void* logits, int is_bf16, const int64_t* targets, con
 // optional segment table: element i uses seg_wd[s] for the first s with seg_ends[s] > i (device arrays)
 void sgd_momentum(float* p, float* g, float* m, void* p_lp, long n, float lr, float mu, float wd,
                   float grad_scale, int zero_grad, int nesterov, const long* seg_ends, const float* seg_wd, int nseg,
+                  const float* grad_scale_dev /* optional device scalar multiplied into grad_scale (clip coefficient) */,
                   hipStream_t st);
 void adamw(float* p, float* g, float* m, float* v, void* p_lp, long n, float lr, float b1, float b2, float eps,
-           float wd, float grad_scale, float bc1, float bc2, int zero_grad, hipStream_t st);
+           float wd, float grad_scale, float bc1, float bc2, int zero_grad, const float* grad_scale_dev, hipStream_t st);
 void cast_f32_to_bf16(const float* x, void* y, long n, hipStream_t st);
 void cast_bf16_to_f32(const void* x, float* y, long n, hipStream_t st);
 void scale_f32(float* x, long n, float s, hipStream_t st);

@@ -30,6 +30,7 @@ class FusedSGD:
         self.flat = flat
         self.lr, self.momentum, self.weight_decay, self.nesterov = lr, momentum, weight_decay, nesterov
         self.grad_scale = 1.0
+        self.clip_coef: Optional[torch.Tensor] = None     # device scalar from clip_grad_norm, consumed by the next step()
         self.momentum_buf = torch.zeros_like(flat.master) if momentum != 0.0 else None
         self.steps = 0
         # contiguous runs of the flat buffer sharing the same weight decay -> one launch each
@@ -65,9 +66,11 @@ class FusedSGD:
                 self._seg_wd = torch.tensor([w for _, _, w in self.segments], dtype=torch.float32, device=f.device)
             # ONE launch over the whole flat buffer
             C.sgd_momentum(f.master, f.grad, self.momentum_buf, f.lp, self.lr, self.momentum, self.segments[0][2], gs,
-                           zero_grad, self.nesterov, self._seg_ends, self._seg_wd)
+                           zero_grad, self.nesterov, self._seg_ends, self._seg_wd, self.clip_coef)
             f.refresh_transposed()          # conv filters' [C,R,S,K] twins for the next backward (one launch)
         else:
+            if self.clip_coef is not None:
+                gs = gs * float(self.clip_coef)
             for a, b, wd in self.segments:
                 p, g = f.master[a:b], f.grad[a:b]
                 d = g * gs
@@ -80,6 +83,7 @@ class FusedSGD:
                 p.add_(d, alpha=-self.lr)
                 if zero_grad:
                     g.zero_()
+        self.clip_coef = None
         self.steps += 1
 
     # ---- torch.optim.SGD-compatible (de)serialisation, parameters in registration order ----
@@ -148,8 +152,10 @@ class ShardedSGD(FusedSGD):
                     self._seg_ends = torch.tensor([b for _, b, _ in self.shard_segments], dtype=torch.int64, device=f.device)
                     self._seg_wd = torch.tensor([w for _, _, w in self.shard_segments], dtype=torch.float32, device=f.device)
                 C.sgd_momentum(p, g, self.momentum_buf, None, self.lr, self.momentum,
-                               self.shard_segments[0][2], gs, False, self.nesterov, self._seg_ends, self._seg_wd)
+                               self.shard_segments[0][2], gs, False, self.nesterov, self._seg_ends, self._seg_wd, self.clip_coef)
             else:
+                if self.clip_coef is not None:
+                    gs = gs * float(self.clip_coef)
                 for a, b, wd in self.shard_segments:
                     d = g[a:b] * gs
                     if wd != 0.0:
@@ -167,6 +173,7 @@ class ShardedSGD(FusedSGD):
         for w in works:
             w.wait()
         f.refresh_lp()                  # bf16 shadows (and the transposed filter twins) from the gathered masters
+        self.clip_coef = None
         self.steps += 1
 
     def _full_momentum(self) -> Optional[torch.Tensor]:
@@ -206,9 +213,40 @@ class FusedAdamW:
         self.v = torch.zeros_like(flat.master)
         self.steps = 0
         self.grad_scale = 1.0
+        self.clip_coef: Optional[torch.Tensor] = None
 
     def zero_grad(self):
         self.flat.zero_grad()
+
+    # ---- torch.optim.AdamW-compatible (de)serialisation: state[i] = {step, exp_avg, exp_avg_sq}, registration order ----
+    def state_dict(self) -> Dict:
+        f = self.flat
+        state = {}
+        if self.steps > 0:
+            for i, p in enumerate(f.params):
+                off, n = f.offsets[i], p.numel()
+                state[i] = {"step": torch.tensor(float(self.steps)),
+                            "exp_avg": self.m[off:off + n].view(p.shape).detach().cpu().clone(),
+                            "exp_avg_sq": self.v[off:off + n].view(p.shape).detach().cpu().clone()}
+        group = dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay, amsgrad=False,
+                     maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                     params=list(range(len(f.params))))
+        return {"state": state, "param_groups": [group], "steps": self.steps}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        f = self.flat
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
+        self.weight_decay = g.get("weight_decay", 0.0)
+        steps = sd.get("steps")
+        for i, st in sd["state"].items():
+            i = int(i)
+            off, n = f.offsets[i], f.params[i].numel()
+            self.m[off:off + n].copy_(st["exp_avg"].reshape(-1).to(f.device))
+            self.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(f.device))
+            if steps is None:
+                steps = int(float(st["step"]))
+        self.steps = int(steps or 0)
 
     @torch.no_grad()
     def step(self, grad_scale: Optional[float] = None, zero_grad: bool = True):
@@ -220,9 +258,11 @@ class FusedAdamW:
             from .ops import _ext, side
             side.join(f.device)
             _ext.load().adamw(f.master, f.grad, self.m, self.v, f.lp, self.lr, b1, b2, self.eps, self.weight_decay, gs,
-                              self.steps, zero_grad)
+                              self.steps, zero_grad, self.clip_coef)
             f.refresh_transposed()
         else:
+            if self.clip_coef is not None:
+                gs = gs * float(self.clip_coef)
             g = f.grad * gs
             self.m.mul_(b1).add_(g, alpha=1 - b1)
             self.v.mul_(b2).addcmul_(g, g, value=1 - b2)
@@ -232,17 +272,22 @@ class FusedAdamW:
             f.master.addcdiv_(mh, vh.sqrt().add_(self.eps), value=-self.lr)
             if zero_grad:
                 f.grad.zero_()
+        self.clip_coef = None
 
 
 # ---------------------------------------------------------------------------- training-loop utilities
 @torch.no_grad()
-def clip_grad_norm(flat: FlatParams, max_norm: float, grad_scale: float = 1.0, shard=None, comm=None) -> torch.Tensor:
+def clip_grad_norm(flat: FlatParams, max_norm: float, grad_scale: float = 1.0, shard=None, comm=None,
+                   optimizer=None) -> torch.Tensor:
     """Global-norm gradient clipping over the flat gradient buffer, after ``DataParallel.finish()`` and before the
     optimizer step.  The buffer holds the SUM over ranks (the ``1 / world`` lives in the optimizer's ``grad_scale``),
     so pass that scale: the norm returned (a device scalar - nothing here synchronises the host) is the norm of the
     mean gradient.  With a sharded optimizer pass ``shard=(lo, hi)`` and the communicator: each rank holds the reduced
-    gradient of its shard only, the squared norms are summed across ranks.  Not in the reference (constant-lr SGD,
-    DP.py:143); GPT-2 training needs it."""
+    gradient of its shard only, the squared norms are summed across ranks.  With ``optimizer`` (FusedSGD / ShardedSGD /
+    FusedAdamW) the clip coefficient is handed to its next ``step()`` as a device scalar and multiplied into the
+    kernel's gradient scale - no pass over the buffer to apply it (GPT-2: 496 MB read + written per step saved);
+    without, the buffer is scaled in place.  Not in the reference (constant-lr SGD, DP.py:143); GPT-2 training
+    needs it."""
     g = flat.grad if shard is None else flat.grad[shard[0]:shard[1]]
     sq = torch.linalg.vector_norm(g).square() if g.numel() else torch.zeros((), device=flat.grad.device)
     if shard is not None and comm is not None and comm.world_size > 1:
@@ -251,7 +296,10 @@ def clip_grad_norm(flat: FlatParams, max_norm: float, grad_scale: float = 1.0, s
         sq = sq[0]
     norm = sq.sqrt() * grad_scale
     coef = (max_norm / (norm + 1e-6)).clamp(max=1.0)
-    g.mul_(coef)
+    if optimizer is not None and hasattr(optimizer, "clip_coef"):
+        optimizer.clip_coef = coef.reshape(1).to(torch.float32)
+    else:
+        g.mul_(coef)
     return norm
 
 

@@ -107,6 +107,38 @@ def split_microbatches(n: int, n_micro: int) -> List[int]:
 
 
 # ---------------------------------------------------------------------------- engine
+class _SlotPool:
+    """Pre-allocated receive slots.  A receive takes a slot of its (shape, dtype); the slot goes back when the
+    micro-batch it carried has been consumed (its backward has run / its gradient has been sent on), so in steady
+    state no receive allocates: a stage holds as many slots per direction as micro-batches are live on it
+    (``schedule.peak_live_microbatches``: 2 for the serial schedule of the reference, S - stage under 1F1B).
+    Re-use is ordered on the device: the communicator makes its stream wait for the compute stream before every
+    grouped call, so a slot is never overwritten under a kernel that still reads it.
+
+    Receives are issued in schedule order on the ONE communication stream, grouped with the send that is adjacent in
+    the schedule (``schedule.group_comm``); posting a receive ahead of the compute before it would queue it in front of
+    this stage's own next send on that stream - a chain of stages each waiting to receive before it may send."""
+
+    def __init__(self):
+        self._free: Dict[Tuple, List[torch.Tensor]] = {}
+        self.allocated = 0
+
+    def take(self, shape: Tuple[int, ...], dtype: torch.dtype, device) -> torch.Tensor:
+        free = self._free.get((tuple(shape), dtype))
+        if free:
+            return free.pop()
+        self.allocated += 1
+        return torch.empty(tuple(shape), dtype=dtype, device=device)
+
+    def give(self, t: Optional[torch.Tensor]) -> None:
+        if t is None or not getattr(t, "_dpa_slot", False):
+            return
+        if t.requires_grad:
+            t.grad = None
+            t.requires_grad_(False)
+        self._free.setdefault((tuple(t.shape), t.dtype), []).append(t)
+
+
 class PipelineStage:
     """One stage of the pipeline, bound to this rank.
 
@@ -127,6 +159,7 @@ class PipelineStage:
         self._in_meta: Optional[Tuple[Tuple[int, ...], torch.dtype]] = None   # trailing shape + dtype of inputs
         self._out_meta_sent = False
         self._pending_sends: List = []
+        self._slots = _SlotPool()
         self.last_loss: Optional[torch.Tensor] = None
         # parameters tied across the first and the last stage (GPT-2's wte: embedding + LM head).  A stage holding only
         # one end exchanges that parameter's gradient with the other end after backward (see _sync_tied)
@@ -209,7 +242,9 @@ class PipelineStage:
                     if self.last:
                         outputs.pop(mb).backward()
                     else:
-                        outputs.pop(mb).backward(grads_in.pop(mb))
+                        g_in = grads_in.pop(mb)
+                        outputs.pop(mb).backward(g_in)
+                        self._slots.give(g_in)
                 if self.first:
                     inputs.pop(mb, None)
         for w in self._pending_sends:
@@ -251,16 +286,19 @@ class PipelineStage:
                 batch_ops.append(("send", y, self.stage + 1))
             elif op == "recv_fwd":
                 shape, dtype = self._in_meta
-                buf = torch.empty((sizes[mb],) + shape, dtype=dtype, device=self.device)
+                buf = self._slots.take((sizes[mb],) + shape, dtype, self.device)
+                buf._dpa_slot = True
                 batch_ops.append(("recv", buf, self.stage - 1))
                 recvs.append(("in", mb, buf))
             elif op == "send_bwd":
                 xin = inputs.pop(mb)
                 g = xin.grad if xin.grad is not None else torch.zeros_like(xin)
                 batch_ops.append(("send", g.contiguous(), self.stage - 1))
+                self._slots.give(xin)         # its backward has run; the slot carries a later micro-batch next
             elif op == "recv_bwd":
                 y = outputs[mb]
-                buf = torch.empty(y.shape, dtype=y.dtype if self.send_dtype is None else self.send_dtype, device=self.device)
+                buf = self._slots.take(tuple(y.shape), y.dtype if self.send_dtype is None else self.send_dtype, self.device)
+                buf._dpa_slot = True
                 batch_ops.append(("recv", buf, self.stage + 1))
                 recvs.append(("grad", mb, buf))
         works = self.comm.batch_p2p(batch_ops)
@@ -279,7 +317,11 @@ class PipelineStage:
                 inputs[mb] = buf
             else:
                 y = outputs[mb]
-                grads_in[mb] = buf if buf.dtype == y.dtype else buf.to(y.dtype)
+                if buf.dtype == y.dtype:
+                    grads_in[mb] = buf
+                else:
+                    grads_in[mb] = buf.to(y.dtype)
+                    self._slots.give(buf)
 
 
 class _NullCtx:
@@ -320,12 +362,25 @@ def run_pipeline_bench(args, world: _comm.Communicator, device: torch.device) ->
         raise SystemExit(f"world size {n} is not a multiple of --pipeline {S}")
     replicas = n // S
     pp_comm, dp_comm, replica, stage = _comm.build_grid(world, replicas, S)
-    if args.model == "mnist":
-        raise SystemExit("bench.py --pipeline: resnet50 / resnet152 / tiny_resnet / gpt2 (the 2-stage MNIST split is examples/mp.py)")
     name = args.model
     tokens = name == "gpt2"
+    small = name == "mnist"
     g = torch.Generator(device=device).manual_seed(1234 + replica)
-    if tokens:
+    if small:
+        # BASELINE config 2 = the reference's model-parallel example (multinode-MP/multinodeMP.py:118-167): Net1 on
+        # stage 0, Net2 on stage 1, SGD lr 0.01 without momentum per stage, batch 256 (the README's run command)
+        from ..models import mnist
+        if S != 2:
+            raise SystemExit("--model mnist --pipeline: the reference split has exactly 2 stages (Net1 | Net2)")
+        batch = args.batch or 256
+        hw, classes = 28, 10
+        x = torch.randn(batch, 1, 28, 28, generator=g, device=device)
+        y = torch.randint(0, 10, (batch,), generator=g, device=device)
+        layers = mnist.mnist_stages()
+        stage_mod = layers[stage].to(device).train()
+        bounds = [(0, 1), (1, 2)]
+        model = None
+    elif tokens:
         from ..models import gpt2
         model = gpt2.gpt2_small()
         classes, seq = model.cfg.vocab_size, args.seq_len
@@ -338,20 +393,26 @@ def run_pipeline_bench(args, world: _comm.Communicator, device: torch.device) ->
         batch = args.batch or 256
         x = torch.randn(batch, 3, hw, hw, generator=g, device=device)
         y = torch.randint(0, classes, (batch,), generator=g, device=device)
-    model = model.to(device).train()
-    layers = model.pipeline_layers()
-    mb = max(1, batch // args.micro_batches)
-    costs = measure_costs(layers, x[:mb]) if device.type == "cuda" else param_costs(layers)
-    # every rank must agree on the split: use stage 0 / replica 0's measurement
-    costs = world.broadcast_object(costs, src=0)
-    bounds = partition_balanced(costs, S)
-    stage_mod = build_stage_module(layers, bounds, stage, model)
-    del model
+    if not small:
+        model = model.to(device).train()
+        layers = model.pipeline_layers()
+        mb = max(1, batch // args.micro_batches)
+        costs = measure_costs(layers, x[:mb]) if device.type == "cuda" else param_costs(layers)
+        # every rank must agree on the split: use stage 0 / replica 0's measurement
+        costs = world.broadcast_object(costs, src=0)
+        bounds = partition_balanced(costs, S)
+        stage_mod = build_stage_module(layers, bounds, stage, model)
+        del model
     dp = DataParallel(stage_mod, dp_comm, bucket_mb=args.bucket_mb, first_bucket_mb=args.first_bucket_mb,
-                      use_sink=not args.no_sink)
-    opt = FusedSGD(dp.flat, lr=0.1, momentum=0.9, weight_decay=1e-4)
+                      use_sink=not args.no_sink, use_lp=not small)
+    if small:
+        from ..models import mnist
+        opt = FusedSGD(dp.flat, lr=0.01, momentum=0.0)                 # MP.py:120,124
+        loss_fn = mnist.nll_loss
+    else:
+        opt = FusedSGD(dp.flat, lr=0.1, momentum=0.9, weight_decay=1e-4)
+        loss_fn = (lambda out, t: ops.softmax_cross_entropy(out.reshape(-1, out.shape[-1]), t.reshape(-1), classes))
     opt.grad_scale = dp.grad_scale
-    loss_fn = (lambda out, t: ops.softmax_cross_entropy(out.reshape(-1, out.shape[-1]), t.reshape(-1), classes))
     eng = PipelineStage(stage_mod, pp_comm, loss_fn, n_micro=args.micro_batches, schedule=args.schedule, dp=dp)
 
     def step():
@@ -375,8 +436,9 @@ def run_pipeline_bench(args, world: _comm.Communicator, device: torch.device) ->
     lossv = float(loss.float().cpu()) if loss is not None else float("nan")
     # the loss lives on the last stage; make rank 0 report it
     lossv = world.all_reduce_scalar(lossv if eng.last and replica == 0 else 0.0, "sum")
-    shape = {"seq_len": seq} if tokens else {"image": f"3x{hw}x{hw}"}
+    shape = {"seq_len": seq} if tokens else {"image": f"{1 if small else 3}x{hw}x{hw}"}
     return {"elapsed": elapsed, "items_per_rank_step": batch * (seq if tokens else 1), "dp_world": replicas, "loss": lossv,
-            "config": dict({"model": "gpt2-small-124M" if tokens else name, "global_batch": batch * replicas,
+            "config": dict({"model": "gpt2-small-124M" if tokens else ("mnist_cnn (Net1 | Net2)" if small else name),
+                            "global_batch": batch * replicas, "slots_allocated": eng._slots.allocated,
                             "parallelism": f"pp{S}xdp{replicas}", "micro_batches": args.micro_batches,
                             "schedule": args.schedule, "stage_bounds": bounds}, **shape)}

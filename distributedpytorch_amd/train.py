@@ -56,7 +56,11 @@ def build_model(name: str):
 
 
 def build_dataset(kind: str, cfg: TrainConfig, classes: int, model=None, device=None):
-    gen = dict(device=device, on_device=device is not None and device.type == "cuda" and cfg.device_data)
+    # the dataset lives on the GPU only with --device-data; otherwise it stays on the host and data.PrefetchLoader
+    # pins each batch and copies it on its own stream (a device handed to a host dataset made every batch a pageable
+    # copy on the compute stream and switched the loader's pinned staging off)
+    on_device = device is not None and device.type == "cuda" and cfg.device_data
+    gen = dict(device=device if on_device else None, on_device=on_device)
     if kind == "mnist":
         return ddata.SyntheticImageDataset(cfg.dataset_size, (1, 28, 28), 10, cfg.seed, **gen)
     if kind == "imagenet":
@@ -74,6 +78,7 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
     device = pick_device(cfg, local_rank)
     dcomm.set_sync_debug(cfg.sync_debug)
     comm = dcomm.init_process_group(cfg.backend, cfg.dist_url, global_rank, world_size, cfg.timeout_s, device)
+    last = None
     try:
         torch.manual_seed(cfg.seed)                      # identical initial replicas (DP.py:138) ...
         model, kind, loss_fn, use_lp, classes = build_model(cfg.model)
@@ -155,7 +160,7 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                     dmetrics.check_reduced_gradients(dp.flat, comm)
                 if cfg.clip_grad_norm > 0:
                     shard = (opt.lo, opt.hi) if cfg.shard_optimizer else None
-                    clip_grad_norm(dp.flat, cfg.clip_grad_norm, opt.grad_scale, shard, comm)
+                    clip_grad_norm(dp.flat, cfg.clip_grad_norm, opt.grad_scale, shard, comm, optimizer=opt)
                 if sched is not None:
                     sched.apply(opt, opt.steps)
                 opt.step()                               # fused: scale, momentum, update, bf16 shadow, zero grad
@@ -171,10 +176,14 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
             if cfg.checkpoint:
                 save_checkpoint(cfg.checkpoint, model, opt, epoch, comm=comm)
         guard.__exit__(None, None, None)
-        return last
-    finally:
-        comm.barrier()
-        dcomm.destroy_process_group()
+    except BaseException:
+        # a failing rank must EXIT, at once and with its own traceback: its peers are blocked in a collective that waits
+        # for it, so a barrier here would hang until the process-group timeout (and mask the error); the launcher sees
+        # the non-zero exit and terminates the rest (launch.SpawnContext.join)
+        raise
+    comm.barrier()
+    dcomm.destroy_process_group()
+    return last
 
 
 def run_mp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig):
@@ -182,6 +191,7 @@ def run_mp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
     device = pick_device(cfg, local_rank)
     dcomm.set_sync_debug(cfg.sync_debug)
     world = dcomm.init_process_group(cfg.backend, cfg.dist_url, global_rank, world_size, cfg.timeout_s, device)
+    loss = None
     try:
         stages = cfg.stages
         replicas = max(1, cfg.dp_replicas)
@@ -190,9 +200,13 @@ def run_mp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
         # ranks beyond stages*replicas idle, like ranks >= 2 in the reference (MP.py:118-124 only uses 0 and 1)
         pp_comm, dp_comm, replica, stage = dcomm.build_grid(world, replicas, stages)
         if stage < 0:
+            # an idle rank leaves now and takes part in nothing timed: parked in a barrier it would hit the process-group
+            # timeout in any run longer than cfg.timeout_s and take the working ranks down with it
             return None
+        active = getattr(world, "active", None) or world     # the ranks that train (== world when none idles)
         torch.manual_seed(cfg.seed)
         from . import ops
+        dataset = None
         if cfg.model == "mnist_cnn":
             from .models import mnist
             full = None
@@ -205,11 +219,24 @@ def run_mp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
         else:
             full, kind, _, use_lp, classes = build_model(cfg.model)
             layers = full.pipeline_layers()
-            bounds = partition_balanced(param_costs(layers), stages)
+            # stages balanced by measured forward+backward TIME on the GPU (rank 0's measurement, so every rank cuts
+            # at the same layers); by parameter count only where nothing can be timed (CPU)
+            if device.type == "cuda":
+                from .parallel.pp import measure_costs
+                full = full.to(device).train()
+                mb = max(1, cfg.batch_size // max(1, cfg.micro_batches))
+                dataset = build_dataset(kind, cfg, classes, full, device)
+                sample = dataset.batch(list(range(min(mb, len(dataset)))))[0].to(device)
+                costs = measure_costs(layers, sample)
+            else:
+                costs = param_costs(layers)
+            costs = active.broadcast_object(costs, src=0)
+            bounds = partition_balanced(costs, stages)
             stage_mod = build_stage_module(layers, bounds, stage, full)
             loss_fn = (lambda out, t: ops.softmax_cross_entropy(out.reshape(-1, out.shape[-1]), t.reshape(-1), classes))
         stage_mod = stage_mod.to(device).train()
-        dataset = build_dataset(kind, cfg, classes, full, device)
+        if dataset is None:
+            dataset = build_dataset(kind, cfg, classes, full, device)
         # every rank walks the SAME un-shuffled loader (MP.py:104-116): stage 0 consumes the data, the
         # last stage the targets; replicas take disjoint shards
         if replicas > 1:
@@ -225,12 +252,14 @@ def run_mp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
         if dp is not None:
             opt.grad_scale = dp.grad_scale
         eng = PipelineStage(stage_mod, pp_comm, loss_fn, n_micro=cfg.micro_batches, schedule=cfg.schedule, dp=dp)
+        start_epoch = 0
         if cfg.resume:
-            load_checkpoint(cfg.resume, stage_mod, None, strict=False, flat=flat)
+            payload = load_checkpoint(cfg.resume, stage_mod, opt, strict=False, flat=flat, stage=stage)
+            start_epoch = int(payload.get("epoch", -1)) + 1
         log = dmetrics.JsonlLogger(cfg.log_json, global_rank, only_rank0=False)
         meter = dmetrics.ThroughputMeter(device)
         loss = None
-        for epoch in range(cfg.epochs):
+        for epoch in range(start_epoch, cfg.epochs):
             meter.reset(); meter.start()
             for step, (x, y) in enumerate(loader):
                 if cfg.steps_per_epoch and step >= cfg.steps_per_epoch:
@@ -243,7 +272,8 @@ def run_mp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                 log.log(kind="mp_epoch", epoch=epoch, loss=float(loss), samples_per_sec=meter.rate() * replicas)
             if cfg.checkpoint:
                 save_checkpoint(cfg.checkpoint, stage_mod, opt, epoch, comm=dp_comm, pipeline_comm=pp_comm)
-        return float(loss) if loss is not None else None
-    finally:
-        world.barrier()
-        dcomm.destroy_process_group()
+    except BaseException:
+        raise                    # exit with the traceback; no barrier on the error path (see run_dp)
+    active.barrier()
+    dcomm.destroy_process_group()
+    return float(loss) if loss is not None else None

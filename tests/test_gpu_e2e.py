@@ -295,12 +295,83 @@ def test_native_rccl_communicator_single_rank():
     out = torch.empty_like(y)
     nc.wait(nc.reduce_scatter(out, y)); torch.testing.assert_close(out, y)
     out.zero_(); nc.wait(nc.all_gather(out, y)); torch.testing.assert_close(out, y)
+    nc.wait(nc.reduce(y, 0)); torch.testing.assert_close(y, ref * 2.0)
+    nc.wait(nc.all_reduce_direct(y, torch.empty(1 << 20, dtype=torch.bfloat16, device=DEV)))      # bf16 wire format
+    torch.testing.assert_close(y, ref * 2.0)
+    t = nc.all_reduce(y, 0)
     nc.synchronize()
+    assert nc.query(t) and C.RcclComm.version() >= 21000
     # the N-way reduction kernel of the direct algorithm: dst += sum of (world - 1) incoming shards
     dst = torch.randn(1003, device=DEV); src = torch.randn(3, 1024, device=DEV)
     want = dst + src[:, :1003].sum(0)
     C.reduce_shards(dst, src.view(-1), 3, 1024)
     torch.testing.assert_close(dst, want)
+    # ... and its bf16-wire twin: fp32 accumulation of bf16 copies, result in fp32 and in bf16
+    dst = torch.randn(1000, device=DEV); srcb = torch.randn(3, 1024, device=DEV).to(torch.bfloat16)
+    want = dst + srcb[:, :1000].float().sum(0)
+    outb = torch.empty(1000, dtype=torch.bfloat16, device=DEV)
+    C.reduce_shards_bf16(dst, srcb.view(-1), 3, 1024, outb)
+    torch.testing.assert_close(dst, want)
+    assert torch.equal(outb, want.to(torch.bfloat16))
+
+
+def test_native_rccl_layer_under_bucket_sized_traffic():
+    """The pattern that stalled round 1's raw-stream version of the communicator (docs/DESIGN.md section 5): five
+    32 MB in-place all-reduces per step, each issued from a side stream behind a producer kernel, all waited for on
+    the compute stream, then a host read - 30 steps, with a host watchdog instead of a hang."""
+    import time
+    from distributedpytorch_amd.ops import _ext
+    C = _ext.load()
+    nc = C.RcclComm(C.RcclComm.unique_id(), 0, 1, torch.cuda.current_device())
+    bufs = [torch.zeros(8 << 20, device=DEV) for _ in range(5)]
+    side = torch.cuda.Stream()
+    for step in range(30):
+        tickets = []
+        for b in bufs:
+            b.add_(1.0)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                b.mul_(1.0)
+                tickets.append(nc.all_reduce(b, 0))
+        for t in tickets:
+            nc.wait(t)
+        t0 = time.monotonic()
+        while not all(nc.query(t) for t in tickets):
+            assert time.monotonic() - t0 < 30.0, f"native communicator stalled in step {step}"
+            time.sleep(0.001)
+        assert sum(float(b[0]) for b in bufs) == 5.0 * (step + 1)
+    nc.synchronize()
+
+
+def test_native_group_single_rank_carries_the_dp_engine(monkeypatch):
+    """init_native_group (store rendezvous, no torch.distributed) at world size 1 with the collectives forced through
+    RCCL: the DataParallel engine's bucket launches, side-stream issue and optimizer ordering on the native layer."""
+    from distributedpytorch_amd import comm as dcomm
+    from distributedpytorch_amd.models.resnet import tiny_resnet
+    from distributedpytorch_amd.parallel.dp import DataParallel
+    from distributedpytorch_amd.optim import FusedSGD
+    from distributedpytorch_amd.utils import testing as T
+    monkeypatch.setattr(dcomm, "_FORCE_COLLECTIVES", True)
+    c = dcomm.init_native_group(f"tcp://127.0.0.1:{T.free_port()}", 0, 1, torch.device(DEV, torch.cuda.current_device()))
+    try:
+        assert c.native is not None and c.world_size == 1 and c.backend == "nccl"
+        torch.manual_seed(0)
+        model = tiny_resnet().to(DEV).train()
+        dp = DataParallel(model, c, bucket_mb=0.25, first_bucket_mb=0.0625)
+        opt = FusedSGD(dp.flat, lr=0.05, momentum=0.9)
+        x = torch.randn(16, 3, 64, 64, device=DEV); y = torch.randint(0, 16, (16,), device=DEV)
+        losses = []
+        for _ in range(6):
+            loss = model.loss(x, y); loss.backward(); dp.finish(); opt.step()
+            losses.append(float(loss))
+        assert dp.stats["allreduce_calls"] >= 6 * len(dp.buckets) and len(dp.buckets) > 1
+        assert losses[-1] < losses[0]
+        assert c.all_reduce_scalar(3.0, "max") == 3.0 and c.broadcast_object({"a": 1}) == {"a": 1}
+        c.barrier()
+    finally:
+        from distributedpytorch_amd.ops import sink
+        sink.uninstall()
+        c.close()
 
 
 @pytest.mark.parametrize("model_name", ["mnist", "tiny_resnet"])

@@ -1,0 +1,58 @@
+"""The TCP rendezvous store (distributedpytorch_amd/store.py): what carries the RCCL unique id when a job runs
+without torch.distributed (comm.init_native_group).  Reference behaviour replaced: c10d's TCPStore behind
+``init_method="tcp://..."`` (multinode-DP/multinodeDP.py:161)."""
+import threading
+import time
+
+import pytest
+
+from distributedpytorch_amd.store import TCPKVStore, parse_tcp_url
+
+
+def test_set_get_add_and_objects_between_clients():
+    master = TCPKVStore("127.0.0.1", 0, is_master=True, timeout_s=10)
+    other = TCPKVStore("127.0.0.1", master.port, is_master=False, timeout_s=10)
+    try:
+        master.set("uid", bytes(range(128)))
+        assert other.get("uid") == bytes(range(128))
+        assert other.add("n", 2) == 2 and master.add("n", 3) == 5
+        other.set_object("o", {"rank": 1, "vals": [1.5, 2.5]})
+        assert master.get_object("o") == {"rank": 1, "vals": [1.5, 2.5]}
+        master.delete("uid")
+        with pytest.raises(TimeoutError):
+            other.get("uid", timeout_s=0.2)
+    finally:
+        other.close()
+        master.close()
+
+
+def test_get_blocks_until_another_client_sets_the_key_and_barrier_releases_everyone():
+    master = TCPKVStore("127.0.0.1", 0, is_master=True, timeout_s=10)
+    clients = [TCPKVStore("127.0.0.1", master.port, is_master=False, timeout_s=10) for _ in range(3)]
+    got, order = {}, []
+
+    def waiter(i):
+        got[i] = clients[i].get("late")
+        clients[i].barrier("b0", 4)
+        order.append(i)
+
+    threads = [threading.Thread(target=waiter, args=(i,)) for i in range(3)]
+    for t in threads:
+        t.start()
+    time.sleep(0.2)
+    assert not got
+    master.set("late", b"x")
+    time.sleep(0.2)
+    assert got == {0: b"x", 1: b"x", 2: b"x"} and not order          # all three are held by the barrier
+    master.barrier("b0", 4)
+    for t in threads:
+        t.join(5)
+    assert sorted(order) == [0, 1, 2]
+    for c in clients:
+        c.close()
+    master.close()
+
+
+def test_parse_tcp_url():
+    assert parse_tcp_url("tcp://10.0.0.3:8885") == ("10.0.0.3", 8885)
+    assert parse_tcp_url("127.0.0.1:29500") == ("127.0.0.1", 29500)
