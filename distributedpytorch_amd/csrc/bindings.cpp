@@ -266,6 +266,52 @@ Tensor bn_bwd_apply(const Tensor& dy, const c10::optional<Tensor>& mask, const T
     return dx;
 }
 
+// Backward of "1x1 conv -> BatchNorm -> ReLU mask" in one kernel (csrc/tail_bwd.hip): the BatchNorm-backward apply pass
+// (co = bn_bwd_coefs(...)), the conv's filter gradient (accumulated into dw) and its input gradient (returned), plus -
+// with bn_x / bn_mask / bn_stats - the reduction pass of the BatchNorm behind the returned gradient, as conv_dgrad does.
+bool tail_bwd_ok(int64_t P, int64_t CM, int64_t CO) {
+    dpa::TailBwdArgs a{};
+    a.P = P; a.CM = (int)CM; a.CO = (int)CO;
+    return dpa::tail_bwd_supported(a);
+}
+Tensor tail_bwd(const Tensor& dout, const c10::optional<Tensor>& kout, const Tensor& craw, const Tensor& co, const Tensor& xin,
+                const Tensor& wt, Tensor& dw, const c10::optional<Tensor>& bn_x, const c10::optional<Tensor>& bn_mask,
+                const c10::optional<Tensor>& bn_stats) {
+    CHECK_BF16(dout); CHECK_BF16(craw); CHECK_BF16(xin); CHECK_BF16(wt); CHECK_F32(co); CHECK_F32(dw);
+    const int64_t CO = craw.size(-1), CM = xin.size(-1), P = craw.numel() / CO;
+    TORCH_CHECK(dout.numel() == craw.numel() && xin.numel() == P * CM, "tail_bwd: dout / craw / xin shapes");
+    TORCH_CHECK(wt.numel() == CM * CO && wt.size(0) == CM && wt.size(-1) == CO, "tail_bwd: wt must be [CM,1,1,CO]");
+    TORCH_CHECK(dw.numel() == CM * CO && dw.size(0) == CO, "tail_bwd: dw must be [CO,1,1,CM]");
+    TORCH_CHECK(co.dim() == 2 && co.size(0) == 5 && co.size(1) == CO, "tail_bwd: co must be bn_bwd_coefs' [5,CO]");
+    dpa::TailBwdArgs a{};
+    a.dout = dout.data_ptr(); a.craw = craw.data_ptr(); a.xin = xin.data_ptr(); a.wt = wt.data_ptr();
+    a.dw = dw.data_ptr<float>();
+    const float* o = co.data_ptr<float>();
+    a.cA = o + 2 * CO; a.cB = o + 3 * CO; a.cC = o + 4 * CO;
+    a.P = P; a.CM = (int)CM; a.CO = (int)CO;
+    if (kout.has_value() && kout->defined()) {
+        TORCH_CHECK(kout->is_cuda() && kout->scalar_type() == at::kByte && kout->is_contiguous() && kout->numel() * 8 == dout.numel(),
+                    "tail_bwd: kout must be uint8 with one bit per element of dout");
+        a.kout = kout->data_ptr<uint8_t>();
+    }
+    TORCH_CHECK(dpa::tail_bwd_supported(a), "tail_bwd: unsupported shape (ask tail_bwd_ok first)");
+    Guard g(dout);
+    std::vector<int64_t> shp(xin.sizes().begin(), xin.sizes().end());
+    Tensor dx = torch::empty(shp, xin.options());
+    a.dx = dx.data_ptr();
+    if (bn_x.has_value() && bn_x->defined()) {
+        TORCH_CHECK(bn_mask.has_value() && bn_mask->defined() && bn_stats.has_value() && bn_stats->defined(), "tail_bwd: bn_mask / bn_stats missing");
+        CHECK_BF16((*bn_x)); CHECK_F32((*bn_stats));
+        TORCH_CHECK(bn_x->numel() == dx.numel() && bn_mask->is_cuda() && bn_mask->scalar_type() == at::kByte && bn_mask->is_contiguous() &&
+                    bn_mask->numel() * 8 == dx.numel(), "tail_bwd: bn_x / bn_mask shapes");
+        TORCH_CHECK(bn_stats->dim() == 3 && bn_stats->size(1) == 2 && bn_stats->size(2) == CM && bn_stats->size(0) >= 1, "tail_bwd: bn_stats must be [rows,2,CM]");
+        a.sx = bn_x->data_ptr(); a.smask = bn_mask->data_ptr<uint8_t>();
+        a.stats = bn_stats->data_ptr<float>(); a.stats_rows = (int)bn_stats->size(0);
+    }
+    dpa::tail_bwd(a, cur_stream());
+    return dx;
+}
+
 // dw [K,R,S,C] fp32 += wgrad(x, dy).  dw must be initialised by the caller.  With dbias (fp32 [K]) the bias
 // gradient dbias += column sums of dy is produced too: inside the wgrad kernel where that variant exists, else by
 // the column-sum kernels.
@@ -404,9 +450,10 @@ std::vector<Tensor> bn_apply(const Tensor& x, const c10::optional<Tensor>& resid
 
 // returns (dx, dgamma, dbeta).  relu: `mask` is the bit mask written by bn_apply (the gradient
 // of a residual branch is dy under the same mask: relu_mask_mul, or the dgrad addend_mask).
-std::vector<Tensor> bn_backward(const Tensor& dy, const c10::optional<Tensor>& mask, const Tensor& x, const Tensor& gamma,
-                                const Tensor& mean, const Tensor& invstd, bool relu, const c10::optional<Tensor>& dgamma_acc,
-                                const c10::optional<Tensor>& dbeta_acc, const c10::optional<Tensor>& stats_buf) {
+// the reduction + finalize half of bn_backward: returns co [5, C] = dgamma, dbeta, cA, cB, cC (dx = cA * dy' + cB * x + cC)
+Tensor bn_backward_coefs(const Tensor& dy, const c10::optional<Tensor>& mask, const Tensor& x, const Tensor& gamma,
+                         const Tensor& mean, const Tensor& invstd, bool relu, const c10::optional<Tensor>& dgamma_acc,
+                         const c10::optional<Tensor>& dbeta_acc, const c10::optional<Tensor>& stats_buf) {
     CHECK_BF16(dy); CHECK_BF16(x); CHECK_F32(gamma); CHECK_F32(mean); CHECK_F32(invstd);
     const int64_t C = x.size(-1), P = x.numel() / C;
     TORCH_CHECK(dy.numel() == x.numel(), "bn_backward: shape mismatch");
@@ -448,8 +495,19 @@ std::vector<Tensor> bn_backward(const Tensor& dy, const c10::optional<Tensor>& m
     }
     dpa::bn_bwd_finalize(stats.data_ptr<float>(), rows, P, C, gamma.data_ptr<float>(), mean.data_ptr<float>(),
                          invstd.data_ptr<float>(), dg, db, accumulate, o + 2 * C, o + 3 * C, o + 4 * C, reset, 0, cur_stream());
+    return co;
+}
+
+std::vector<Tensor> bn_backward(const Tensor& dy, const c10::optional<Tensor>& mask, const Tensor& x, const Tensor& gamma,
+                                const Tensor& mean, const Tensor& invstd, bool relu, const c10::optional<Tensor>& dgamma_acc,
+                                const c10::optional<Tensor>& dbeta_acc, const c10::optional<Tensor>& stats_buf) {
+    Tensor co = bn_backward_coefs(dy, mask, x, gamma, mean, invstd, relu, dgamma_acc, dbeta_acc, stats_buf);
+    const int64_t C = x.size(-1), P = x.numel() / C;
+    Guard g(x);
+    const float* o = co.data_ptr<float>();
     Tensor dx = torch::empty_like(x);
-    dpa::bn_bwd_apply(dy.data_ptr(), mk, x.data_ptr(), o + 2 * C, o + 3 * C, o + 4 * C, dx.data_ptr(), P, C, relu, cur_stream());
+    dpa::bn_bwd_apply(dy.data_ptr(), relu ? mask->data_ptr<uint8_t>() : nullptr, x.data_ptr(), o + 2 * C, o + 3 * C, o + 4 * C,
+                      dx.data_ptr(), P, C, relu, cur_stream());
     return {dx, co[0], co[1]};
 }
 
@@ -799,6 +857,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("addend"), py::arg("addend_mask"), py::arg("bn_x") = py::none(), py::arg("bn_mask") = py::none(),
           py::arg("bn_stats") = py::none(), py::arg("gelu_x") = py::none());
     m.def("bn_bwd_apply", &bn_bwd_apply);
+    m.def("bn_backward_coefs", &bn_backward_coefs);
+    m.def("tail_bwd_ok", &tail_bwd_ok);
+    m.def("tail_bwd", &tail_bwd, py::arg("dout"), py::arg("kout"), py::arg("craw"), py::arg("co"), py::arg("xin"), py::arg("wt"),
+          py::arg("dw"), py::arg("bn_x") = py::none(), py::arg("bn_mask") = py::none(), py::arg("bn_stats") = py::none());
     m.def("conv_fprop_stats", &conv_fprop_stats);
     m.def("conv_bn_res_relu", &conv_bn_res_relu);
     m.def("conv_bnb_stats", &conv_bnb_stats);

@@ -70,6 +70,24 @@ void conv_wgrad(const WgradArgs& a, hipStream_t st);
 // true when conv_wgrad's kernel for this problem also produces a.dbias (else the caller runs colsum_bf16)
 bool conv_wgrad_fuses_bias(const WgradArgs& a);
 
+// Backward of "1x1 conv (CM -> CO = 4 CM channels) -> BatchNorm -> ReLU mask" in one kernel (tail_bwd.hip):
+//   g = cA * (dout under kout) + cB * craw + cC  (never stored);  dw += g^T xin;  dx = g w;
+//   optionally the reduction pass of the BatchNorm behind dx: stats += (sum dx', sum dx' * sx), dx' = dx under smask
+struct TailBwdArgs {
+    const void* dout;            // bf16 [P][CO]
+    const unsigned char* kout;   // 1 bit per element of dout, or nullptr (no mask)
+    const void* craw;            // bf16 [P][CO]  the BatchNorm's input (raw conv output)
+    const float* cA; const float* cB; const float* cC;   // fp32 [CO]  (bn_bwd_finalize)
+    const void* xin;             // bf16 [P][CM]  the conv's input
+    const void* wt;              // bf16 [CM][CO] the conv's filter with K and C swapped
+    float* dw;                   // fp32 [CO][CM] accumulated into (atomics)
+    void* dx;                    // bf16 [P][CM]
+    const void* sx; const unsigned char* smask; float* stats; int stats_rows;   // all four or none ([rows][2][CM])
+    long P; int CM, CO;
+};
+bool tail_bwd_supported(const TailBwdArgs& a);
+void tail_bwd(const TailBwdArgs& a, hipStream_t st);
+
 // [K, RS, C] bf16 -> [C, RS, K] bf16 (filter for dgrad)
 void transpose_filter(const void* w, void* wt, int K, int RS, int C, hipStream_t st);
 // all filters of a model in one launch; table [nconv][6] int64 on device = (src off, dst off, K, RS, C, first tile)

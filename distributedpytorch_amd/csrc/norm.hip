@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
         }
         float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = cA[ch * 8 + j] * g[j] + cB[ch * 8 + j] * xf[j] + cC[ch * 8 + j];
+        for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(cA[ch * 8 + j], g[j], __builtin_fmaf(cB[ch * 8 + j], xf[j], cC[ch * 8 + j]));   // same association as tail_bwd.hip
         *(uint4*)(dx + i * 8) = pack8(o);
     }
 }
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const unsigned s
         pool_grad_gather(dp, idx, n, hi, wi, ch, Ho, Wo, cpr, g);
         { const uint4 v = *(const uint4*)(x + (size_t)i * 8); unpack8(v, xf); }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = cA[ch * 8 + j] * g[j] + cB[ch * 8 + j] * xf[j] + cC[ch * 8 + j];
+        for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(cA[ch * 8 + j], g[j], __builtin_fmaf(cB[ch * 8 + j], xf[j], cC[ch * 8 + j]));   // same association as tail_bwd.hip
         *(uint4*)(dx + (size_t)i * 8) = pack8(o);
     }
 }

@@ -73,6 +73,53 @@ def _bn_bwd(C, bn, dy, mask, x_raw, mean, invstd, relu, grads, slot):
 
 _DGRAD_BN_STATS = os.environ.get("DPA_NO_DGRAD_BN_STATS", "0") != "1"
 _CROSS_BN3 = _DGRAD_BN_STATS and os.environ.get("DPA_NO_CROSS_BN3", "0") != "1"
+_TAIL_BWD = os.environ.get("DPA_NO_TAIL_BWD", "0") != "1"
+
+
+def _bn_coefs(C, bn, dy, mask, x_raw, mean, invstd, grads, slot):
+    """Reduction pass + finalize of a BatchNorm(+ReLU) backward WITHOUT the apply pass: co [5, C] (rows 2..4 = cA, cB, cC);
+    the parameter gradients go to the sink or into ``grads``."""
+    tg, tb = _sink.target(bn.weight), _sink.target(bn.bias)
+    sunk = tg is not None and tb is not None
+    co = C.bn_backward_coefs(dy, mask, x_raw, bn.weight.detach(), mean, invstd, True, tg if sunk else None,
+                             tb if sunk else None, bn.stats_buffer_bwd(dy.device))
+    if sunk:
+        _sink.ready(bn.weight); _sink.ready(bn.bias)
+    else:
+        grads[slot], grads[slot + 1] = co[0], co[1]
+    return co
+
+
+def _coefs_from_stats(C, bn, sb, P, mean, invstd, grads, slot):
+    """Finalize of a BatchNorm backward whose reduction pass was accumulated into ``sb`` by a conv epilogue."""
+    tg, tb = _sink.target(bn.weight), _sink.target(bn.bias)
+    sunk = tg is not None and tb is not None
+    co = C.bn_bwd_coefs(sb, P, bn.weight.detach(), mean, invstd, tg if sunk else None, tb if sunk else None)
+    if sunk:
+        _sink.ready(bn.weight); _sink.ready(bn.bias)
+    else:
+        grads[slot], grads[slot + 1] = co[0], co[1]
+    return co
+
+
+def _tail_ok(C, conv, x_in, dout):
+    """The one-kernel backward of ``1x1 conv -> BatchNorm -> mask`` (csrc/tail_bwd.hip) covers this layer."""
+    return (_TAIL_BWD and conv.stride == 1 and conv.padding == 0 and conv.weight_lp.shape[1] == 1
+            and x_in.shape[:3] == dout.shape[:3]
+            and C.tail_bwd_ok(dout.numel() // dout.shape[-1], x_in.shape[-1], dout.shape[-1]))
+
+
+def _tail_bwd(C, conv, co, dout, kout, craw, x_in, grads, slot, bn_x=None, bn_mask=None, bn_stats=None):
+    """g = BatchNorm-backward apply(dout under kout, craw; co), never stored; conv.weight's gradient += g^T x_in (sink or
+    ``grads[slot]``); returns g @ w, with the reduction pass of the BatchNorm behind it added into ``bn_stats``."""
+    tgt = _sink.target(conv.weight)
+    dw = tgt if tgt is not None else torch.zeros(conv.weight.shape, dtype=torch.float32, device=dout.device)
+    dx = C.tail_bwd(dout, kout, craw, co, x_in, _wt(C, conv), dw, bn_x, bn_mask, bn_stats)
+    if tgt is not None:
+        _sink.ready(conv.weight)
+    else:
+        grads[slot] = dw
+    return dx
 
 
 def _dgrad_then_bn_bwd(C, conv, bn, dy, hw, mask, x_raw, mean, invstd, grads, slot):
@@ -211,6 +258,10 @@ class _BottleneckFn(torch.autograd.Function):
             dconv_ = blk.downsample[0]
 
             def ds_branch():
+                if _tail_ok(C, dconv_, x, dout):
+                    co_ = _bn_coefs(C, blk.downsample[1], dout, k3, cd_, md_, isd_, grads, 10)
+                    ds_box.append(_tail_bwd(C, dconv_, co_, dout, k3, cd_, x, grads, 9))
+                    return
                 dd_ = _bn_bwd(C, blk.downsample[1], dout, k3, cd_, md_, isd_, True, grads, 10)
                 _wgrad(C, dconv_, x, dd_, grads, 9, in_line=True)
                 ds_box.append(C.conv_dgrad(dd_, _wt(C, dconv_), x.shape[1], x.shape[2], dconv_.stride, 0, None, None))
@@ -229,31 +280,39 @@ class _BottleneckFn(torch.autograd.Function):
             else:
                 grads[7], grads[8] = co[0], co[1]
             d3 = C.conv_bnb_apply(a2, w3, 1, 0, dout, k3, co[2], co[3], co[4])
-        elif ctx.link.stats_for is not None:
-            # the block after this one already accumulated bn3's reduction pass while writing dout (_CROSS_BN3)
-            sb = blk.bn3.stats_buffer_bwd(dout.device)
-            if ctx.link.stats_for == (dout.data_ptr(), tuple(dout.shape)):
-                tg, tb = _sink.target(blk.bn3.weight), _sink.target(blk.bn3.bias)
-                sunk = tg is not None and tb is not None
-                co = C.bn_bwd_coefs(sb, dout.numel() // dout.shape[-1], blk.bn3.weight.detach(), m3, i3,
-                                    tg if sunk else None, tb if sunk else None)
-                if sunk:
-                    _sink.ready(blk.bn3.weight); _sink.ready(blk.bn3.bias)
-                else:
-                    grads[7], grads[8] = co[0], co[1]
-                d3 = C.bn_bwd_apply(dout, k3, c3, co, True)
-            else:                       # dout is not the tensor those statistics were taken from (another consumer
-                sb.zero_()              # of the block output added its gradient): discard them
-                d3 = _bn_bwd(C, blk.bn3, dout, k3, c3, m3, i3, True, grads, 7)
-            ctx.link.stats_for = None
         else:
-            d3 = _bn_bwd(C, blk.bn3, dout, k3, c3, m3, i3, True, grads, 7)
+            co3 = None
+            if ctx.link.stats_for is not None:
+                # the block after this one already accumulated bn3's reduction pass while writing dout (_CROSS_BN3)
+                sb = blk.bn3.stats_buffer_bwd(dout.device)
+                if ctx.link.stats_for == (dout.data_ptr(), tuple(dout.shape)):
+                    co3 = _coefs_from_stats(C, blk.bn3, sb, dout.numel() // dout.shape[-1], m3, i3, grads, 7)
+                else:                   # dout is not the tensor those statistics were taken from (another consumer
+                    sb.zero_()          # of the block output added its gradient): discard them
+                ctx.link.stats_for = None
+            if co3 is None:
+                co3 = _bn_coefs(C, blk.bn3, dout, k3, c3, m3, i3, grads, 7)
+            if _tail_ok(C, blk.conv3, a2, dout):
+                # stage 1: bn3's apply pass, conv3's wgrad and dgrad and bn2's reduction pass in ONE kernel - the
+                # gradient of the block's widest tensor is read once and never written (csrc/tail_bwd.hip)
+                d3 = None
+                if _DGRAD_BN_STATS:
+                    sb2 = blk.bn2.stats_buffer_bwd(dout.device)
+                    da2 = _tail_bwd(C, blk.conv3, co3, dout, k3, c3, a2, grads, 6, c2, k2, sb2)
+                    co2 = _coefs_from_stats(C, blk.bn2, sb2, da2.numel() // da2.shape[-1], m2, i2, grads, 4)
+                    d2 = C.bn_bwd_apply(da2, k2, c2, co2, True)
+                else:
+                    da2 = _tail_bwd(C, blk.conv3, co3, dout, k3, c3, a2, grads, 6)
+                    d2 = _bn_bwd(C, blk.bn2, da2, k2, c2, m2, i2, True, grads, 4)
+            else:
+                d3 = C.bn_bwd_apply(dout, k3, c3, co3, True)
         ctx.link.c3 = ctx.link.k3 = None
         # each wgrad goes to the side stream BEFORE the dgrad that shares its operand is enqueued: the two GEMMs
         # run side by side and the wgrad's tail overlaps the next BatchNorm backward (measured better than
         # enqueueing it after the dgrad, and better than keeping the HBM-bound stage-1/2 1x1 wgrads in line)
-        _wgrad(C, blk.conv3, a2, d3, grads, 6)
-        d2 = _dgrad_then_bn_bwd(C, blk.conv3, blk.bn2, d3, a2.shape[1:3], k2, c2, m2, i2, grads, 4)
+        if d3 is not None:
+            _wgrad(C, blk.conv3, a2, d3, grads, 6)
+            d2 = _dgrad_then_bn_bwd(C, blk.conv3, blk.bn2, d3, a2.shape[1:3], k2, c2, m2, i2, grads, 4)
         _wgrad(C, blk.conv2, a1, d2, grads, 3)
         d1 = _dgrad_then_bn_bwd(C, blk.conv2, blk.bn1, d2, a1.shape[1:3], k1, c1, m1, i1, grads, 1)
         _wgrad(C, blk.conv1, x, d1, grads, 0)
@@ -270,10 +329,14 @@ class _BottleneckFn(torch.autograd.Function):
         elif ds:
             cd, md, isd = sv[15:18]
             dconv = blk.downsample[0]
-            dd = _bn_bwd(C, blk.downsample[1], dout, k3, cd, md, isd, True, grads, 10)   # "relu" = the join's mask
-            _wgrad(C, dconv, x, dd, grads, 9)
+            if need_dx and _tail_ok(C, dconv, x, dout):
+                cod = _bn_coefs(C, blk.downsample[1], dout, k3, cd, md, isd, grads, 10)
+                dxd = _tail_bwd(C, dconv, cod, dout, k3, cd, x, grads, 9)
+            else:
+                dd = _bn_bwd(C, blk.downsample[1], dout, k3, cd, md, isd, True, grads, 10)   # "relu" = the join's mask
+                _wgrad(C, dconv, x, dd, grads, 9)
+                dxd = C.conv_dgrad(dd, _wt(C, dconv), x.shape[1], x.shape[2], dconv.stride, 0, None, None) if need_dx else None
             if need_dx:
-                dxd = C.conv_dgrad(dd, _wt(C, dconv), x.shape[1], x.shape[2], dconv.stride, 0, None, None)
                 dx = C.conv_dgrad(d1, _wt(C, blk.conv1), x.shape[1], x.shape[2], 1, 0, dxd, None, *bn_args)
         elif need_dx:
             # identity shortcut: the masked residual gradient is added in the dgrad epilogue
