@@ -14,3 +14,16 @@ from .data import Partition, DataPartitioner, partition_dataset, BatchLoader  # 
 from .config import TrainConfig, parse_dp, parse_mp  # noqa: F401
 
 __version__ = "0.1.0"
+
+
+def set_deterministic(on: bool = True) -> None:
+    """Bit-reproducible gradients for debugging (also ``DPA_DETERMINISTIC=1``): every float-atomic accumulation in the
+    kernels (pixel-split wgrad, BatchNorm statistics in conv epilogues, the fused bottleneck tail, embedding
+    gradients, the loss sum) takes a single-writer / fixed-order route instead.  Slower; see csrc/runtime.hip."""
+    from .ops import _ext
+    _ext.load().set_deterministic(bool(on))
+
+
+def is_deterministic() -> bool:
+    from .ops import _ext
+    return bool(_ext.load().deterministic())

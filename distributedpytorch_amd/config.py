@@ -57,9 +57,7 @@ class TrainConfig:
     device_data: bool = False      # synthetic image batches generated on the GPU instead of on the host
     # ---- model / data ----
     model: str = "mnist_cnn"
-    dataset: str = "synthetic"
     dataset_size: int = 60000
-    dtype: str = "auto"            # auto: bf16 on GPU for big models, fp32 for the MNIST nets
     # ---- engine ----
     bucket_mb: float = 32.0
     first_bucket_mb: float = 4.0
@@ -119,7 +117,6 @@ def _common_flags(p: argparse.ArgumentParser) -> None:
     p.add_argument("--model", default=None, type=str)
     p.add_argument("--dataset-size", default=60000, type=int)
     p.add_argument("--steps-per-epoch", default=None, type=int)
-    p.add_argument("--dtype", default="auto", type=str)
     p.add_argument("--device", default="auto", type=str)
     p.add_argument("--checkpoint", default=None, type=str, help="path to write a state_dict checkpoint")
     p.add_argument("--resume", default=None, type=str, help="path of a checkpoint to resume from")
@@ -185,7 +182,7 @@ def config_from_args(args: argparse.Namespace, mode: str) -> TrainConfig:
         momentum=args.momentum if args.momentum is not None else defaults["momentum"],
         weight_decay=args.weight_decay, seed=args.seed, workers=args.workers,
         model=args.model or defaults["model"], dataset_size=args.dataset_size,
-        steps_per_epoch=args.steps_per_epoch, dtype=args.dtype, device=args.device,
+        steps_per_epoch=args.steps_per_epoch, device=args.device,
         checkpoint=args.checkpoint, resume=args.resume, log_json=args.log_json,
         timeout_s=args.timeout, sync_debug=args.sync_debug, device_data=args.device_data,
     )

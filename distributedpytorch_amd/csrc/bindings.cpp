@@ -28,6 +28,23 @@ struct Guard {
 
 // ---------------------------------------------------------------- conv
 // x [N,H,W,C] bf16, w [K,R,S,C] bf16 -> y [N,Ho,Wo,K] bf16 (+ optional BN partial stats [rows,2,K])
+// DPA_DETERMINISTIC (csrc/runtime.hip): statistics that a conv epilogue adds with float atomics into a few replica rows go to
+// one row per contributing workgroup instead (a single add per entry: order-free) and are folded in a fixed order into
+// row 0 of the caller's accumulator afterwards.
+struct DetStats {
+    Tensor tmp, user;
+    void redirect(float*& ptr, int& rows, const Tensor& user_buf, int64_t slots) {
+        if (!dpa::deterministic() || ptr == nullptr) return;
+        user = user_buf;
+        tmp = torch::zeros({slots, user_buf.size(1), user_buf.size(2)}, user_buf.options());
+        ptr = tmp.data_ptr<float>(); rows = (int)slots;
+    }
+    void finish() {
+        if (user.defined()) user.select(0, 0).add_(tmp.sum(0));
+    }
+};
+static int64_t det_slots(int64_t rows_out, int64_t stride) { return ((rows_out + 63) / 64 + 1) * stride * stride; }
+
 // `addend` (bf16, the output's shape): y = conv(x) + bias + addend - a residual connection in the GEMM epilogue.
 std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias, int64_t stride,
                                int64_t pad, int64_t act, bool want_stats, const c10::optional<Tensor>& stats_buf,
@@ -54,6 +71,7 @@ std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::opti
         a.bias = bias->data_ptr<float>();
     }
     Tensor stats;
+    DetStats det;
     a.stats = nullptr;
     const int64_t M = N * Ho * Wo;
     a.stats_rows = 0; a.addend = nullptr;
@@ -68,6 +86,7 @@ std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::opti
         }
         a.stats = stats.data_ptr<float>();
         a.stats_rows = stats.size(0);
+        det.redirect(a.stats, a.stats_rows, stats, det_slots(M, 1));
     }
     if (addend.has_value() && addend->defined()) {
         CHECK_BF16((*addend));
@@ -83,6 +102,7 @@ std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::opti
         a.y_act = y_act.data_ptr();
     }
     dpa::conv_igemm(a, cur_stream());
+    det.finish();
     if (want_stats) return {y, stats};
     if (gelu_twin) return {y, y_act};
     return {y};
@@ -124,7 +144,10 @@ void conv_fprop_stats(const Tensor& x, const Tensor& w, int64_t stride, int64_t 
     check_stats_buf(stats_buf, a.K);
     Guard g(x);
     a.y = nullptr; a.stats = stats_buf.data_ptr<float>(); a.stats_rows = stats_buf.size(0);
+    DetStats det;
+    det.redirect(a.stats, a.stats_rows, stats_buf, det_slots((int64_t)a.N * a.Ho * a.Wo, 1));
     dpa::conv_igemm(a, cur_stream());
+    det.finish();
 }
 
 // out = relu(conv(x, w) * scale + shift + residual), plus its 1-bit mask
@@ -152,7 +175,10 @@ void conv_bnb_stats(const Tensor& x, const Tensor& w, int64_t stride, int64_t pa
     Guard g(x);
     a.y = nullptr; a.epi = 2; a.ep_src = dout.data_ptr(); a.ep_mask_in = check_mask(mask, a);
     a.ep_stats = stats_buf.data_ptr<float>(); a.ep_stats_rows = stats_buf.size(0);
+    DetStats det;
+    det.redirect(a.ep_stats, a.ep_stats_rows, stats_buf, det_slots((int64_t)a.N * a.Ho * a.Wo, 1));
     dpa::conv_igemm(a, cur_stream());
+    det.finish();
 }
 
 // BN backward, apply pass: d(conv out) = cA * g + cB * c + cC with c recomputed
@@ -212,6 +238,7 @@ Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int6
     Guard g(dy);
     Tensor dx = torch::empty({N, H, W, C}, dy.options());
     dpa::ConvArgs a{};
+    DetStats det;
     a.x = dy.data_ptr(); a.w = wt.data_ptr(); a.y = dx.data_ptr(); a.bias = nullptr; a.stats = nullptr;
     a.stats_rows = 0; a.addend = nullptr;
     TORCH_CHECK(dy.numel() < (1ll << 30) && wt.numel() < (1ll << 30) && N * H * W * C < (1ll << 31) - 16,
@@ -236,6 +263,7 @@ Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int6
         TORCH_CHECK(bn_stats->dim() == 3 && bn_stats->size(1) == 2 && bn_stats->size(2) == C, "conv_dgrad: bn_stats must be [rows,2,C]");
         a.epi = 4; a.ep_src = bn_x->data_ptr(); a.ep_mask_in = bn_mask->data_ptr<uint8_t>();
         a.ep_stats = bn_stats->data_ptr<float>(); a.ep_stats_rows = (int)bn_stats->size(0);
+        det.redirect(a.ep_stats, a.ep_stats_rows, *bn_stats, det_slots(N * H * W, stride));
     }
     if (gelu_x.has_value() && gelu_x->defined()) {
         CHECK_BF16((*gelu_x));
@@ -244,6 +272,7 @@ Tensor conv_dgrad(const Tensor& dy, const Tensor& wt, int64_t H, int64_t W, int6
         a.epi = 5; a.ep_src = gelu_x->data_ptr();
     }
     dpa::conv_igemm(a, cur_stream());
+    det.finish();
     return dx;
 }
 
@@ -468,7 +497,7 @@ Tensor bn_backward_coefs(const Tensor& dy, const c10::optional<Tensor>& mask, co
     auto fopt = x.options().dtype(at::kFloat);
     int rows; int replicas = 0; int reset = 0;
     Tensor stats;
-    if (stats_buf.has_value() && stats_buf->defined()) {     // persistent zeroed accumulator (re-zeroed by the finalize kernel)
+    if (stats_buf.has_value() && stats_buf->defined() && !dpa::deterministic()) {     // persistent zeroed accumulator (re-zeroed by the finalize kernel)
         stats = *stats_buf;
         CHECK_F32(stats);
         TORCH_CHECK(stats.dim() == 3 && stats.size(1) == 2 && stats.size(2) == C, "bn_backward: stats_buf must be [rows,2,C]");
@@ -549,11 +578,15 @@ std::vector<Tensor> pool_bn_backward(const Tensor& dp, const Tensor& idx, const 
                 "pool_bn_backward: channels");
     TORCH_CHECK(stats_buf.dim() == 3 && stats_buf.size(1) == 2 && stats_buf.size(2) == C, "pool_bn_backward: stats_buf must be [rows,2,C]");
     Guard g(x);
-    const int rows = stats_buf.size(0);
+    int rows = stats_buf.size(0);
     const int64_t P = N * H * W;
     Tensor stats = stats_buf;
+    if (dpa::deterministic()) {        // one partial row per workgroup (plain stores), folded in order by the finalize kernel
+        rows = dpa::bn_stats_rows(P);
+        stats = torch::empty({rows, 2, C}, stats_buf.options());
+    }
     dpa::pool_bn_bwd_stats(dp.data_ptr(), idx.data_ptr<uint8_t>(), x.data_ptr(), mean.data_ptr<float>(), invstd.data_ptr<float>(),
-                           stats.data_ptr<float>(), N, H, W, C, Ho, Wo, rows, cur_stream());
+                           stats.data_ptr<float>(), N, H, W, C, Ho, Wo, dpa::deterministic() ? 0 : rows, cur_stream());
     Tensor co = torch::empty({5, C}, x.options().dtype(at::kFloat));
     float* o = co.data_ptr<float>();
     float* dg = o; float* db = o + C; int accumulate = 0;
@@ -651,6 +684,11 @@ std::vector<Tensor> softmax_ce_fwd(const Tensor& logits, const Tensor& targets, 
     Tensor loss = torch::zeros({1}, fopt), lse = torch::empty({B}, fopt);
     dpa::softmax_ce_fwd(logits.data_ptr(), bf, targets.data_ptr<int64_t>(), lse.data_ptr<float>(), loss.data_ptr<float>(),
                         B, V, ld, (float)scale, ignore_index, cur_stream());
+    if (dpa::deterministic()) {     // the kernel adds one term per row with a float atomic: re-sum them in a fixed order
+        Tensor valid = (targets != ignore_index).logical_and(targets >= 0).logical_and(targets < V);
+        Tensor picked = logits.narrow(1, 0, V).gather(1, targets.clamp(0, V - 1).unsqueeze(1)).squeeze(1).to(at::kFloat);
+        loss = ((lse - picked) * valid.to(at::kFloat)).sum().mul(scale).reshape({1});
+    }
     return {loss, lse};
 }
 
@@ -857,6 +895,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("addend"), py::arg("addend_mask"), py::arg("bn_x") = py::none(), py::arg("bn_mask") = py::none(),
           py::arg("bn_stats") = py::none(), py::arg("gelu_x") = py::none());
     m.def("bn_bwd_apply", &bn_bwd_apply);
+    m.def("set_deterministic", [](bool on) { dpa::set_deterministic(on); });
+    m.def("deterministic", []() { return dpa::deterministic(); });
     m.def("bn_backward_coefs", &bn_backward_coefs);
     m.def("tail_bwd_ok", &tail_bwd_ok);
     m.def("tail_bwd", &tail_bwd, py::arg("dout"), py::arg("kout"), py::arg("craw"), py::arg("co"), py::arg("xin"), py::arg("wt"),

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256, igemm_waves_per_simd(WP, ONE, STG)) void conv_
         lid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
     }
     const int tile_c = lid % tiles_c, tile_p = lid / tiles_c;
+    const int stat_slot = tile_p * (int)gridDim.y + (int)blockIdx.y;   // replica row of the statistics epilogues (parity classes apart)
     const long m0 = (long)tile_p * BP;
     if (m0 >= M) return;                   // MODE 2: classes differ in size; block-uniform exit
     const int c0 = tile_c * BC;
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(256, igemm_waves_per_simd(WP, ONE, STG)) void conv_
             const float sm = r == 0 ? Sm[0] : r == 1 ? Sm[1] : r == 2 ? Sm[2] : Sm[3];
             const int ch = c0 + cb * 16 + li;
             if ((li >> 2) == kg && ch < a.K) {
-                float* dst = a.stats + (long)(tile_p % a.stats_rows) * 2 * a.K + ch;
+                float* dst = a.stats + (long)(stat_slot % a.stats_rows) * 2 * a.K + ch;
                 atomicAdd(dst, sm);
                 atomicAdd(dst + a.K, q);
             }
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256, igemm_waves_per_simd(WP, ONE, STG)) void conv_
 #pragma unroll 8
             for (int r = 0; r < RPP; ++r) t += red[(st_ * RPP + r) * BC + ch];
             if (c0 + ch < a.K)
-                atomicAdd(a.ep_stats + ((long)(tile_p % a.ep_stats_rows) * 2 + st_) * a.K + c0 + ch, t);
+                atomicAdd(a.ep_stats + ((long)(stat_slot % a.ep_stats_rows) * 2 + st_) * a.K + c0 + ch, t);
         }
     };
     if (epi_on) {

@@ -374,6 +374,7 @@ void launch(const WgradArgs& a, hipStream_t st) {
     // (chip-wide float-atomic rate is ~1.3 TB/s), so do not over-split large filters.
     int split = wgrad_target_blocks() / tiles;
     if (split < 1) split = 1;
+    if (deterministic()) split = 1;            // one writer per dw element: no float atomics race (runtime.hip)
     int max_split = steps / 8;
     if (max_split < 1) max_split = 1;
     if (split > max_split) split = max_split;

@@ -6,6 +6,10 @@
 
 namespace dpa {
 
+// ---------------------------------------------------------------- switches (runtime.hip)
+bool deterministic();            // DPA_DETERMINISTIC=1: single-writer routes instead of float atomics (bit-reproducible)
+void set_deterministic(bool on);
+
 // ---------------------------------------------------------------- conv / GEMM
 // Implicit-GEMM convolution on NHWC bf16 activations and KRSC bf16 filters.
 //   mode 0 (fprop):  y[n,ho,wo,k] = sum_{r,s,c} x[n, ho*stride-pad+r, wo*stride-pad+s, c] * w[k,r,s,c]

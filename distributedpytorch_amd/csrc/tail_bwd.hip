@@ -109,23 +109,23 @@ __global__ __launch_bounds__(256, 1) void tail_bwd_kernel(TailBwdArgs a, int ste
 
     u32x4 dreg[8], creg[8], xreg[2], sreg[2];
     unsigned mreg[8], smr[2];
-#define TB_LOAD()                                                                                           \
+#define TB_LOAD_HALF(H)                                                                                     \
     {                                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                     \
+        _Pragma("unroll") for (int i = 4 * (H); i < 4 * (H) + 4; ++i) {                                     \
             const unsigned o = d_goff + (unsigned)(i * 8 * D_ROWB);                                         \
             dreg[i] = __builtin_amdgcn_raw_buffer_load_b128(dors, o, 0, 0);                                 \
             creg[i] = __builtin_amdgcn_raw_buffer_load_b128(crrs, o, 0, 0);                                 \
             mreg[i] = a.kout ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(kors, o >> 4, 0, 0) : 0xffu;   \
         }                                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                     \
-            const unsigned o = x_goff + (unsigned)(i * 32 * X_ROWB);                                        \
-            xreg[i] = __builtin_amdgcn_raw_buffer_load_b128(xirs, o, 0, 0);                                 \
+        {                                                                                                   \
+            const unsigned o = x_goff + (unsigned)((H) * 32 * X_ROWB);                                      \
+            xreg[H] = __builtin_amdgcn_raw_buffer_load_b128(xirs, o, 0, 0);                                 \
             if (STATS) {                                                                                    \
-                sreg[i] = __builtin_amdgcn_raw_buffer_load_b128(sxrs, o, 0, 0);                             \
-                smr[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(smrs, o >> 4, 0, 0);                 \
+                sreg[H] = __builtin_amdgcn_raw_buffer_load_b128(sxrs, o, 0, 0);                             \
+                smr[H] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(smrs, o >> 4, 0, 0);                 \
             }                                                                                               \
         }                                                                                                   \
-        d_goff += (unsigned)(TB_R * D_ROWB); x_goff += (unsigned)(TB_R * X_ROWB);                           \
+        if (H) { d_goff += (unsigned)(TB_R * D_ROWB); x_goff += (unsigned)(TB_R * X_ROWB); }                \
     }
 
     // ---- wgrad roles: wave = 64 out channels x all 64 in channels; transposed reads as in conv_wgrad.hip ----
@@ -164,10 +164,12 @@ __global__ __launch_bounds__(256, 1) void tail_bwd_kernel(TailBwdArgs a, int ste
 #pragma unroll
     for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; qsum[j] = 0.f; }
 
-    TB_LOAD()
+    TB_LOAD_HALF(0)
+    TB_LOAD_HALF(1)
     __syncthreads();                                    // filter + coefficients visible
     for (int t = 0; t < nsteps; ++t) {
         const long row_base = p_begin + (long)t * TB_R;
+        u32x4 sxe[2]; unsigned sme[2];
         // ---- BatchNorm-backward apply on the way into LDS ----
         {
             float kA[8], kB[8], kC[8];
@@ -178,33 +180,33 @@ __global__ __launch_bounds__(256, 1) void tail_bwd_kernel(TailBwdArgs a, int ste
                 kB[0] = b0.x; kB[1] = b0.y; kB[2] = b0.z; kB[3] = b0.w; kB[4] = b1.x; kB[5] = b1.y; kB[6] = b1.z; kB[7] = b1.w;
                 kC[0] = c0.x; kC[1] = c0.y; kC[2] = c0.z; kC[3] = c0.w; kC[4] = c1.x; kC[5] = c1.y; kC[6] = c1.z; kC[7] = c1.w;
             }
+            // the tile arrives in two halves (rows 0..31, 32..63), each re-issued for tile t + 1 as soon as its registers
+            // are free: the load stream never drains while this workgroup transforms and multiplies
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float dv[8], cv[8], o[8];
-                unpack8(uint4{dreg[i].x, dreg[i].y, dreg[i].z, dreg[i].w}, dv);
-                unpack8(uint4{creg[i].x, creg[i].y, creg[i].z, creg[i].w}, cv);
-                const unsigned m = mreg[i];
-                const bool live = row_base + d_row0 + 8 * i < p_end;
+            for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float gd = ((m >> j) & 1u) ? dv[j] : 0.f;
-                    const float v = __builtin_fmaf(kA[j], gd, __builtin_fmaf(kB[j], cv[j], kC[j]));   // as bn_bwd_apply_kernel
-                    o[j] = live ? v : 0.f;
+                for (int i = 4 * h; i < 4 * h + 4; ++i) {
+                    float dv[8], cv[8], o[8];
+                    unpack8(uint4{dreg[i].x, dreg[i].y, dreg[i].z, dreg[i].w}, dv);
+                    unpack8(uint4{creg[i].x, creg[i].y, creg[i].z, creg[i].w}, cv);
+                    const unsigned m = mreg[i];
+                    const bool live = row_base + d_row0 + 8 * i < p_end;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float gd = ((m >> j) & 1u) ? dv[j] : 0.f;
+                        const float v = __builtin_fmaf(kA[j], gd, __builtin_fmaf(kB[j], cv[j], kC[j]));   // as bn_bwd_apply_kernel
+                        o[j] = live ? v : 0.f;
+                    }
+                    const uint4 pk = pack8(o);
+                    *(u32x4*)(dimg + d_lds[i]) = u32x4{pk.x, pk.y, pk.z, pk.w};
                 }
-                const uint4 pk = pack8(o);
-                *(u32x4*)(dimg + d_lds[i]) = u32x4{pk.x, pk.y, pk.z, pk.w};
+                *(u32x4*)(ximg + x_lds[h]) = xreg[h];
+                if (STATS) { sxe[h] = sreg[h]; sme[h] = smr[h]; }
+                __builtin_amdgcn_sched_barrier(0);
+                if (h == 0) TB_LOAD_HALF(0) else TB_LOAD_HALF(1)      // past p_end: zeros, never used
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) *(u32x4*)(ximg + x_lds[i]) = xreg[i];
         }
-        u32x4 sxe[2]; unsigned sme[2];
-        if (STATS) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) { sxe[i] = sreg[i]; sme[i] = smr[i]; }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        TB_LOAD()                                       // tile t + 1 flies during the MFMA phase (past p_end: zeros)
-        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
 
         // ---- wgrad: dw[co][cm] += g^T xin over the tile's 64 pixels ----
@@ -294,13 +296,13 @@ __global__ __launch_bounds__(256, 1) void tail_bwd_kernel(TailBwdArgs a, int ste
         }
     }
 }
-#undef TB_LOAD
+#undef TB_LOAD_HALF
 
 }  // namespace
 
 bool tail_bwd_supported(const TailBwdArgs& a) {
     static const bool off = [] { const char* e = getenv("DPA_NO_TAIL_BWD"); return e && atoi(e) != 0; }();
-    return !off && a.CM == TB_CM && a.CO == TB_CO && a.P > 0 && a.P * (long)TB_CO * 2 < (1ll << 31) - (1ll << 20);
+    return !off && !deterministic() && a.CM == TB_CM && a.CO == TB_CO && a.P > 0 && a.P * (long)TB_CO * 2 < (1ll << 31) - (1ll << 20);
 }
 
 void tail_bwd(const TailBwdArgs& a, hipStream_t st) {
@@ -314,7 +316,8 @@ void tail_bwd(const TailBwdArgs& a, hipStream_t st) {
         }
         prepared = true;
     }
-    static const int target = [] { const char* e = getenv("DPA_TAIL_BWD_BLOCKS"); return e ? atoi(e) : 512; }();
+    // one workgroup per CU (83 KiB of LDS each): 254 us at 256 workgroups, 264 us at 512 on the stage-1 shape
+    static const int target = [] { const char* e = getenv("DPA_TAIL_BWD_BLOCKS"); return e ? atoi(e) : 256; }();
     const long steps = (a.P + TB_R - 1) / TB_R;
     long grid = steps < target ? steps : target;
     const int spw = (int)((steps + grid - 1) / grid);

@@ -10,6 +10,12 @@ optimizer).  Operand tensors are kept referenced until the side stream has passe
 allocator cannot hand their memory to a later compute-stream kernel.
 
 ``DPA_WGRAD_STREAM=0`` disables it (everything on the compute stream, the measured baseline).
+
+State lives in one ``SideStream`` object per DEVICE (the stream, the operands it still reads, whether anything is
+in flight).  That is deliberately not per engine: stream order is a property of the device queue, ``join`` has to
+cover every producer of a gradient whichever engine launched it, and two engines on one GPU gain nothing from two
+side queues (HIP maps them onto the same few hardware queues).  What IS per engine - where a gradient lands and
+who is told it is ready - lives in ``ops/sink.py``'s ``GradSink`` objects.
 """
 from __future__ import annotations
 
@@ -21,45 +27,65 @@ import torch
 
 ENABLED = os.environ.get("DPA_WGRAD_STREAM", "1") != "0"
 
-_streams: Dict[int, "torch.cuda.Stream"] = {}
-_pending: Deque[Tuple["torch.cuda.Event", int, tuple]] = deque()
-_dirty: Dict[int, bool] = {}
-_callback_queued = False
+
+class SideStream:
+    """The side queue of one device."""
+
+    def __init__(self, index: int):
+        self.index = index
+        self.stream = torch.cuda.Stream(device=index)
+        self.pending: Deque[Tuple["torch.cuda.Event", tuple]] = deque()   # (done, operands kept alive)
+        self.dirty = False
+        self.callback_queued = False
+
+    def run(self, fn: Callable[[], None], keep: Sequence[torch.Tensor]) -> "torch.cuda.Event":
+        self.stream.wait_stream(torch.cuda.current_stream(self.index))
+        with torch.cuda.stream(self.stream):
+            fn()
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        self.pending.append((done, tuple(keep)))
+        self.dirty = True
+        if not self.callback_queued:                    # whoever reads gradients right after backward() is covered too
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+                self.callback_queued = True
+            except RuntimeError:                        # not inside a backward pass
+                pass
+        while self.pending and self.pending[0][0].query():      # drop references the side stream is done with
+            self.pending.popleft()
+        return done
+
+    def join(self) -> None:
+        if not self.dirty:
+            return
+        self.dirty = False
+        torch.cuda.current_stream(self.index).wait_stream(self.stream)
+        self.pending.clear()    # whatever those kernels read may be recycled by compute-stream allocations: they run after the join
+
+    def _end_of_backward(self) -> None:
+        self.callback_queued = False
+        self.join()
+
+
+_per_device: Dict[int, SideStream] = {}
+
+
+def for_device(index: int) -> SideStream:
+    s = _per_device.get(index)
+    if s is None:
+        s = _per_device[index] = SideStream(index)
+    return s
 
 
 def active(t: torch.Tensor) -> bool:
     return ENABLED and t.is_cuda and not torch.cuda.is_current_stream_capturing()
 
 
-def _stream(index: int) -> "torch.cuda.Stream":
-    s = _streams.get(index)
-    if s is None:
-        s = _streams[index] = torch.cuda.Stream(device=index)
-    return s
-
-
 def run(fn: Callable[[], None], keep: Sequence[torch.Tensor]) -> "torch.cuda.Event":
-    """Launch ``fn`` (which enqueues kernels reading ``keep``) on the side stream, after everything enqueued
-    on the current stream so far.  Returns the event marking its completion (see ``wait``)."""
-    index = keep[0].device.index
-    side = _stream(index)
-    side.wait_stream(torch.cuda.current_stream(index))
-    with torch.cuda.stream(side):
-        fn()
-        done = torch.cuda.Event()
-        done.record(side)
-    _pending.append((done, index, tuple(keep)))
-    _dirty[index] = True
-    global _callback_queued
-    if not _callback_queued:                        # whoever reads gradients right after backward() is covered too
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
-            _callback_queued = True
-        except RuntimeError:                        # not inside a backward pass
-            pass
-    while _pending and _pending[0][0].query():      # drop references the side stream is done with
-        _pending.popleft()
-    return done
+    """Launch ``fn`` (which enqueues kernels reading ``keep``) on the side stream of ``keep[0]``'s device, after
+    everything enqueued on the current stream so far.  Returns the event marking its completion (see ``wait``)."""
+    return for_device(keep[0].device.index).run(fn, keep)
 
 
 class on_side_stream:
@@ -72,12 +98,12 @@ class on_side_stream:
         self.ctx = None
 
     def __enter__(self):
-        side = _stream(self.index)
-        side.wait_stream(torch.cuda.current_stream(self.index))
-        _dirty[self.index] = True
-        self.ctx = torch.cuda.stream(side)
+        side = for_device(self.index)
+        side.stream.wait_stream(torch.cuda.current_stream(self.index))
+        side.dirty = True
+        self.ctx = torch.cuda.stream(side.stream)
         self.ctx.__enter__()
-        return side
+        return side.stream
 
     def __exit__(self, *exc):
         return self.ctx.__exit__(*exc)
@@ -95,22 +121,10 @@ def wait(done: "torch.cuda.Event", produced: Sequence[torch.Tensor] = ()) -> Non
 
 
 def join(device=None) -> None:
-    """Order the current stream behind all side-stream work enqueued so far (no host block)."""
-    if not _dirty:
-        return
+    """Order the current stream behind all side-stream work enqueued so far on ``device`` (no host block)."""
     index = torch.cuda.current_device() if device is None else torch.device(device).index
-    if not _dirty.pop(index, False):
-        return
-    torch.cuda.current_stream(index).wait_stream(_streams[index])
-    # whatever those kernels read may now be recycled by compute-stream allocations: they run after the join
-    for _ in range(len(_pending)):
-        item = _pending.popleft()
-        if item[1] != index:
-            _pending.append(item)
-
-
-def _end_of_backward() -> None:
-    global _callback_queued
-    _callback_queued = False
-    for index in list(_dirty):
-        join(torch.device("cuda", index))
+    if index is None:
+        index = torch.cuda.current_device()
+    s = _per_device.get(index)
+    if s is not None:
+        s.join()

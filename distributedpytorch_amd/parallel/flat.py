@@ -162,16 +162,25 @@ class FlatParams:
                 p.grad = self._grad_views[id(p)]
 
     def install_sink(self, ready_cb=None) -> None:
-        """Let wgrad kernels accumulate straight into the flat gradient buffer."""
-        _sink.install({pid: g for pid, g in self._grad_views.items()}, ready_cb)
+        """Let wgrad kernels accumulate straight into THIS flat gradient buffer (ops/sink.py: the sink object hangs off
+        the parameters it covers, so other FlatParams in the process keep theirs)."""
+        self.uninstall_sink()
+        self.sink = _sink.GradSink(self.params, self._grad_views, ready_cb)
+
+    def uninstall_sink(self) -> None:
+        s = getattr(self, "sink", None)
+        if s is not None:
+            s.uninstall()
+        self.sink = None
 
     # ------------------------------------------------------------------ buckets
     def plan_buckets(self, bucket_bytes: int, first_bucket_bytes: Optional[int] = None) -> List["Bucket"]:
         """Contiguous slices of the flat gradient buffer in backward-readiness order.
         Buckets only close on parameter boundaries.  ``first_bucket_bytes`` bounds the
-        FIRST bucket (ready earliest - starts communication early); the LAST bucket
-        (first layers, un-overlappable tail) is whatever remains and is kept small by
-        capping it to ``first_bucket_bytes`` as well when possible."""
+        FIRST bucket (ready earliest - starts communication early) and the LAST one
+        (first layers: nothing is left to overlap it with, so its collective is
+        exposed): the trailing parameters that fit ``first_bucket_bytes`` are split off
+        the final bucket when it is larger than that."""
         return plan_buckets([self.params[i].numel() for i in self.order],
                             [self.offsets[i] for i in self.order], self.order, self.total,
                             bucket_bytes, first_bucket_bytes)
@@ -210,4 +219,17 @@ def plan_buckets(numels: List[int], offsets: List[int], order: List[int], total:
         cur_elems += n
     if cur_params:
         buckets.append(Bucket(cur_start, total, cur_params))
+    # cap the LAST bucket (the un-overlappable tail): split the trailing parameters that fit first_cap off it
+    if first_bucket_bytes and buckets and len(buckets[-1].param_indices) > 1:
+        last = buckets[-1]
+        n_last = len(last.param_indices)
+        first_pos = len(order) - n_last                     # flat position of the bucket's first parameter
+        if sum(numels[first_pos:]) > first_cap:
+            tail, k = 0, len(order)
+            while k - 1 > first_pos and tail + numels[k - 1] <= first_cap:
+                k -= 1
+                tail += numels[k]
+            if first_pos < k < len(order):
+                buckets[-1] = Bucket(last.start, offsets[k], last.param_indices[:k - first_pos])
+                buckets.append(Bucket(offsets[k], total, last.param_indices[k - first_pos:]))
     return buckets

@@ -80,8 +80,6 @@ def test_fused_block_matches_op_by_op_path(two_pass_shortcut):
         finally:
             block.ENABLED = True
             block.RECOMPUTE_MIN_BYTES = keep
-            from distributedpytorch_amd.ops import sink
-            sink.uninstall()
         grads.append((float(loss.detach()), flat.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters()}))
     for (l1, g1, d1), (l2, g2, d2) in ((grads[0], grads[1]), (grads[2], grads[1])):
         _compare_paths(l1, g1, d1, l2, g2, d2)
@@ -136,7 +134,7 @@ def test_side_stream_wgrad_matches_in_line_wgrad():
     """Weight gradients launched on the side stream (ops/side.py) equal the in-line ones, and are complete when
     backward() returns (end-of-backward join) as well as after DataParallel.finish()."""
     from distributedpytorch_amd.models import resnet
-    from distributedpytorch_amd.ops import side, sink
+    from distributedpytorch_amd.ops import side
     from distributedpytorch_amd.parallel.dp import DataParallel
     x = torch.randn(16, 3, 64, 64, device=DEV); y = torch.randint(0, 16, (16,), device=DEV)
     got = []
@@ -151,7 +149,6 @@ def test_side_stream_wgrad_matches_in_line_wgrad():
             g_after_backward = dp.flat.grad.clone()
             dp.finish()
             got.append((g_after_backward, dp.flat.grad.clone()))
-            sink.uninstall()
     finally:
         side.ENABLED = keep
     (a0, a1), (b0, b1) = got
@@ -160,13 +157,40 @@ def test_side_stream_wgrad_matches_in_line_wgrad():
     assert cos > 0.999 and ((a1 - b1).norm() / b1.norm()).item() < 0.05, cos
 
 
+def test_two_engines_in_one_process_each_fill_their_own_flat_buffer():
+    """Two DataParallel wrappers alive at once: the gradient sink hangs off the parameters, so the
+    second engine does not steal the first one's kernels' output - interleaved backward passes land in the right
+    flat buffers and equal what each model produces alone."""
+    from distributedpytorch_amd.models import resnet
+    from distributedpytorch_amd.parallel.dp import DataParallel
+    x = torch.randn(8, 3, 64, 64, device=DEV); y = torch.randint(0, 16, (8,), device=DEV)
+
+    def build(seed):
+        torch.manual_seed(seed)
+        m = resnet.tiny_resnet().to(DEV).train()
+        return m, DataParallel(m)
+
+    solo = []
+    for seed in (11, 12):
+        m, dp = build(seed)
+        m.loss(x, y).backward(); dp.finish()
+        solo.append(dp.flat.grad.clone())
+    (m1, dp1), (m2, dp2) = build(11), build(12)          # both alive, both with a sink installed
+    l1, l2 = m1.loss(x, y), m2.loss(x, y)
+    l2.backward(); l1.backward()
+    dp1.finish(); dp2.finish()
+    for got, want in ((dp1.flat.grad, solo[0]), (dp2.flat.grad, solo[1])):
+        assert float(got.norm()) > 0
+        assert ((got - want).norm() / want.norm()).item() < 2e-2       # atomics' summation order only
+
+
 def test_block_output_with_a_second_consumer_falls_back_to_standalone_bn3_statistics(two_pass_shortcut):
     """The next block folds bn3's backward reduction into its last dgrad only if bn3's incoming gradient IS the
     tensor that dgrad wrote.  With an auxiliary consumer of the block output autograd sums two gradients: the folded
     statistics must be discarded (and the accumulator re-zeroed) - gradients equal the op-by-op path."""
     from distributedpytorch_amd import ops
     from distributedpytorch_amd.models import resnet
-    from distributedpytorch_amd.ops import block, sink
+    from distributedpytorch_amd.ops import block
     from distributedpytorch_amd.parallel.flat import FlatParams
     x = torch.randn(8, 3, 64, 64, device=DEV); y = torch.randint(0, 16, (8,), device=DEV)
     res = []
@@ -188,7 +212,6 @@ def test_block_output_with_a_second_consumer_falls_back_to_standalone_bn3_statis
                 loss.backward()
         finally:
             block.ENABLED = True
-            sink.uninstall()
         res.append((float(loss.detach()), flat.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters()}))
     _compare_paths(*res[0], *res[1])
 
@@ -369,8 +392,6 @@ def test_native_group_single_rank_carries_the_dp_engine(monkeypatch):
         assert c.all_reduce_scalar(3.0, "max") == 3.0 and c.broadcast_object({"a": 1}) == {"a": 1}
         c.barrier()
     finally:
-        from distributedpytorch_amd.ops import sink
-        sink.uninstall()
         c.close()
 
 
