@@ -775,57 +775,94 @@ Tensor cast_bf16_to_f32(const Tensor& x) {
 }
 
 // ---------------------------------------------------------------- MNIST nets (fp32 NCHW)
-std::vector<Tensor> conv5_pool_relu_fwd(const Tensor& x, const Tensor& w, const Tensor& b, const c10::optional<Tensor>& drop) {
+// dropout drawn inside the kernels: p, seed, offset and an optional device step counter (hipGraph-replay safe)
+static const int64_t* step_ptr(const c10::optional<Tensor>& step) {
+    if (!(step.has_value() && step->defined())) return nullptr;
+    TORCH_CHECK(step->is_cuda() && step->scalar_type() == at::kLong && step->numel() == 1, "step must be a device int64 scalar");
+    return step->data_ptr<int64_t>();
+}
+// weight / bias gradient destinations: the caller's accumulators (flat gradient buffer slices) or fresh tensors
+static void grad_dst(const c10::optional<Tensor>& acc, const Tensor& like, bool zero, Tensor& out, bool& accumulate) {
+    if (acc.has_value() && acc->defined()) {
+        CHECK_F32((*acc)); TORCH_CHECK(acc->numel() == like.numel(), "gradient accumulator size");
+        out = *acc; accumulate = true;
+    } else {
+        out = zero ? torch::zeros_like(like) : torch::empty_like(like); accumulate = false;
+    }
+}
+
+std::vector<Tensor> conv5_pool_relu_fwd(const Tensor& x, const Tensor& w, const Tensor& b, double drop_p, int64_t seed,
+                                        int64_t offset, const c10::optional<Tensor>& step) {
     CHECK_F32(x); CHECK_F32(w); CHECK_F32(b);
     TORCH_CHECK(x.dim() == 4 && w.dim() == 4 && w.size(2) == 5 && w.size(3) == 5 && w.size(1) == x.size(1), "conv5: shapes");
     const int64_t N = x.size(0), Cin = x.size(1), H = x.size(2), W = x.size(3), Cout = w.size(0);
     TORCH_CHECK(H >= 6 && W >= 6 && (H - 4) % 2 == 0 && (W - 4) % 2 == 0 && b.numel() == Cout, "conv5: geometry");
-    const float* dm = nullptr;
-    if (drop.has_value() && drop->defined()) { CHECK_F32((*drop)); TORCH_CHECK(drop->numel() == N * Cout, "drop mask"); dm = drop->data_ptr<float>(); }
+    TORCH_CHECK(drop_p >= 0.0 && drop_p < 1.0, "conv5: dropout probability");
     Guard g(x);
     Tensor y = torch::empty({N, Cout, (H - 4) / 2, (W - 4) / 2}, x.options());
     Tensor idx = torch::empty(y.sizes(), x.options().dtype(at::kByte));
     dpa::conv5_pool_relu_fwd(x.data_ptr<float>(), w.data_ptr<float>(), b.data_ptr<float>(), y.data_ptr<float>(),
-                             idx.data_ptr<uint8_t>(), N, Cin, H, W, Cout, dm, cur_stream());
+                             idx.data_ptr<uint8_t>(), N, Cin, H, W, Cout, (float)drop_p, (uint64_t)seed, (uint64_t)offset,
+                             step_ptr(step), cur_stream());
     return {y, idx};
 }
 
+// returns (dx, dw, db); with dw_acc / db_acc the filter gradients are ADDED there instead (gradient sink) and returned as is
 std::vector<Tensor> conv5_pool_relu_bwd(const Tensor& x, const Tensor& w, const Tensor& dy, const Tensor& y, const Tensor& idx,
-                                        const c10::optional<Tensor>& drop, bool need_dx) {
+                                        double gscale, bool need_dx, const c10::optional<Tensor>& dw_acc,
+                                        const c10::optional<Tensor>& db_acc) {
     CHECK_F32(x); CHECK_F32(w); CHECK_F32(dy); CHECK_F32(y); CHECK_DEV(idx); CHECK_CONTIG(idx);
     const int64_t N = x.size(0), Cin = x.size(1), H = x.size(2), W = x.size(3), Cout = w.size(0);
     TORCH_CHECK(dy.numel() == y.numel() && idx.numel() == y.numel() && idx.scalar_type() == at::kByte, "conv5 bwd: shapes");
     TORCH_CHECK(y.numel() == N * Cout * ((H - 4) / 2) * ((W - 4) / 2), "conv5 bwd: geometry");
-    const float* dm = nullptr;
-    if (drop.has_value() && drop->defined()) { CHECK_F32((*drop)); dm = drop->data_ptr<float>(); }
     Guard g(x);
-    Tensor dw = torch::zeros_like(w), db = torch::zeros({Cout}, w.options()), dx;   // accumulated with atomics
+    Tensor dw, db, dx; bool acc_w, acc_b;
+    grad_dst(dw_acc, w, true, dw, acc_w);                     // accumulated with atomics either way
+    grad_dst(db_acc, torch::empty({Cout}, w.options()), true, db, acc_b);
     if (need_dx) dx = torch::empty_like(x);
     dpa::conv5_pool_relu_bwd(x.data_ptr<float>(), w.data_ptr<float>(), dy.data_ptr<float>(), y.data_ptr<float>(),
                              idx.data_ptr<uint8_t>(), need_dx ? dx.data_ptr<float>() : nullptr, dw.data_ptr<float>(),
-                             db.data_ptr<float>(), N, Cin, H, W, Cout, dm, cur_stream());
+                             db.data_ptr<float>(), N, Cin, H, W, Cout, (float)gscale, cur_stream());
     return {dx, dw, db};
 }
 
-Tensor linear_f32_fwd(const Tensor& x, const Tensor& w, const Tensor& b, bool relu) {
+Tensor linear_f32_fwd(const Tensor& x, const Tensor& w, const Tensor& b, bool relu, double drop_p, int64_t seed, int64_t offset,
+                      const c10::optional<Tensor>& step) {
     CHECK_F32(x); CHECK_F32(w); CHECK_F32(b);
     TORCH_CHECK(x.dim() == 2 && w.dim() == 2 && w.size(1) == x.size(1) && b.numel() == w.size(0), "linear_f32: shapes");
+    TORCH_CHECK(drop_p >= 0.0 && drop_p < 1.0, "linear_f32: dropout probability");
     Guard g(x);
     Tensor y = torch::empty({x.size(0), w.size(0)}, x.options());
     dpa::linear_f32_fwd(x.data_ptr<float>(), w.data_ptr<float>(), b.data_ptr<float>(), y.data_ptr<float>(), x.size(0),
-                        x.size(1), w.size(0), relu, cur_stream());
+                        x.size(1), w.size(0), relu, (float)drop_p, (uint64_t)seed, (uint64_t)offset, step_ptr(step), cur_stream());
     return y;
 }
 
-std::vector<Tensor> linear_f32_bwd(const Tensor& x, const Tensor& w, const Tensor& y, const Tensor& dy, bool relu, bool need_dx) {
+// logp = log_softmax(x @ w^T + b, dim=1) in one kernel (classifier heads with <= 64 classes)
+Tensor linear_log_softmax_fwd(const Tensor& x, const Tensor& w, const Tensor& b) {
+    CHECK_F32(x); CHECK_F32(w); CHECK_F32(b);
+    TORCH_CHECK(x.dim() == 2 && w.dim() == 2 && w.size(1) == x.size(1) && b.numel() == w.size(0) && w.size(0) <= 64, "linear_log_softmax: shapes");
+    Guard g(x);
+    Tensor y = torch::empty({x.size(0), w.size(0)}, x.options());
+    dpa::linear_lsm_fwd(x.data_ptr<float>(), w.data_ptr<float>(), b.data_ptr<float>(), y.data_ptr<float>(), x.size(0), x.size(1),
+                        w.size(0), cur_stream());
+    return y;
+}
+
+// (dx, dw, db) in one launch.  lsm: y = log-probabilities, dy = gradient w.r.t. them.  dw_acc / db_acc as for the conv.
+std::vector<Tensor> linear_f32_bwd(const Tensor& x, const Tensor& w, const Tensor& y, const Tensor& dy, bool relu, double gscale,
+                                   bool lsm, bool need_dx, const c10::optional<Tensor>& dw_acc, const c10::optional<Tensor>& db_acc) {
     CHECK_F32(x); CHECK_F32(w); CHECK_F32(y); CHECK_F32(dy);
     TORCH_CHECK(dy.sizes() == y.sizes() && y.size(0) == x.size(0) && y.size(1) == w.size(0), "linear_f32 bwd: shapes");
     Guard g(x);
-    Tensor dw = torch::empty_like(w), db = torch::empty({w.size(0)}, w.options()), dx;
+    Tensor dw, db, dx; bool acc_w, acc_b;
+    grad_dst(dw_acc, w, false, dw, acc_w);
+    grad_dst(db_acc, torch::empty({w.size(0)}, w.options()), false, db, acc_b);
+    TORCH_CHECK(acc_w == acc_b, "linear_f32 bwd: pass both accumulators or neither");
     if (need_dx) dx = torch::empty_like(x);
     dpa::linear_f32_bwd(x.data_ptr<float>(), w.data_ptr<float>(), y.data_ptr<float>(), dy.data_ptr<float>(),
                         need_dx ? dx.data_ptr<float>() : nullptr, dw.data_ptr<float>(), db.data_ptr<float>(), x.size(0),
-                        x.size(1), w.size(0), relu, cur_stream());
+                        x.size(1), w.size(0), relu, (float)gscale, lsm, acc_w, cur_stream());
     return {dx, dw, db};
 }
 
@@ -935,6 +972,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("cast_f32_to_bf16", &cast_f32_to_bf16);
     m.def("cast_bf16_to_f32", &cast_bf16_to_f32);
     m.def("conv5_pool_relu_fwd", &conv5_pool_relu_fwd);
+    m.def("linear_log_softmax_fwd", &linear_log_softmax_fwd);
     m.def("conv5_pool_relu_bwd", &conv5_pool_relu_bwd);
     m.def("linear_f32_fwd", &linear_f32_fwd);
     m.def("linear_f32_bwd", &linear_f32_bwd);

@@ -121,6 +121,17 @@ __device__ __forceinline__ float gelu_tanh_fast(float x) {
     return 0.5f * x * (1.f + t);
 }
 
+// Counter-hash RNG (splitmix64) for dropout: keep-or-drop decision of element i of the stream (seed, offset) - a pure
+// function, so forward kernels draw their masks in line and nothing is stored.  Returns 0 or 1/(1-p).
+__device__ __forceinline__ float dropout_keep(uint64_t seed, uint64_t offset, uint64_t i, float p, float keep_scale) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (i + offset + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+    return u >= p ? keep_scale : 0.f;
+}
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace dpa

@@ -294,14 +294,7 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ m
                                                            const int64_t* __restrict__ step) {
     const float keep_scale = 1.f / (1.f - p);
     if (step != nullptr) offset += (uint64_t)step[0] * 2000003ull;
-    GRID_STRIDE(i, n) {
-        uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + offset + 1);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        z = z ^ (z >> 31);
-        const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
-        mask[i] = u >= p ? keep_scale : 0.f;
-    }
+    GRID_STRIDE(i, n) mask[i] = dropout_keep(seed, offset, (uint64_t)i, p, keep_scale);
 }
 
 }  // namespace

@@ -194,16 +194,24 @@ void attention_bwd(const void* qkv, const void* out, const void* dout, const flo
                    int B, int T, int H, int D, hipStream_t st);
 
 // ---------------------------------------------------------------- small MNIST CNN (fp32, NCHW; reference model)
-// y = relu(maxpool2(conv5x5(x) + b)) fused ; idx = argmax position in the 2x2 window
+// y = dropout2d(relu(maxpool2(conv5x5(x) + b))) fused ; idx = argmax position in the 2x2 window.  drop_p > 0: one keep/drop
+// draw per (sample, channel) from the counter hash (seed, offset + *step * 2000003, n * Cout + co); nothing is stored
 void conv5_pool_relu_fwd(const float* x, const float* w, const float* b, float* y, uint8_t* idx,
-                         int N, int Cin, int H, int W, int Cout, const float* drop_mask, hipStream_t st);
+                         int N, int Cin, int H, int W, int Cout, float drop_p, uint64_t seed, uint64_t offset,
+                         const int64_t* step, hipStream_t st);
+// dw / db are ADDED to (atomics); gscale = 1/(1-p) of the forward's dropout (a dropped channel has y == 0 by itself)
 void conv5_pool_relu_bwd(const float* x, const float* w, const float* dy, const float* y, const uint8_t* idx,
                          float* dx, float* dw, float* db, int N, int Cin, int H, int W, int Cout,
-                         const float* drop_mask, hipStream_t st);
-// y = act(x @ w^T + b) fp32 small GEMM (rows x in -> rows x out)
-void linear_f32_fwd(const float* x, const float* w, const float* b, float* y, int rows, int in, int out, int relu, hipStream_t st);
+                         float gscale, hipStream_t st);
+// y = dropout(act(x @ w^T + b)) fp32 small GEMM (rows x in -> rows x out); element dropout drawn in line as above
+void linear_f32_fwd(const float* x, const float* w, const float* b, float* y, int rows, int in, int out, int relu,
+                    float drop_p, uint64_t seed, uint64_t offset, const int64_t* step, hipStream_t st);
+// logp = log_softmax(x @ w^T + b), out <= 64
+void linear_lsm_fwd(const float* x, const float* w, const float* b, float* logp, int rows, int in, int out, hipStream_t st);
+// one launch: dx (may be nullptr) | dw, db (overwritten, or added to with accumulate).  lsm: y holds log-probabilities and
+// dy is the gradient w.r.t. them (log-softmax backward in line); else relu / gscale as for the conv
 void linear_f32_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* db,
-                    int rows, int in, int out, int relu, hipStream_t st);
+                    int rows, int in, int out, int relu, float gscale, int lsm, int accumulate, hipStream_t st);
 void log_softmax_fwd(const float* x, float* y, int rows, int V, hipStream_t st);
 void log_softmax_bwd(const float* dy, const float* y, float* dx, int rows, int V, hipStream_t st);
 void nll_fwd(const float* logp, const int64_t* t, float* loss, int rows, int V, hipStream_t st);

@@ -1,15 +1,21 @@
 // fp32 NCHW kernels for the reference's MNIST networks (Net / Net1 / Net2).
 //
 // The whole model is ~0.5 MMAC per sample, i.e. launch-latency bound on MI355X, so
-// the design goal is FEW launches, not MFMA tiling: conv + bias + 2x2 max-pool +
-// ReLU (+ channel dropout) is one kernel forward and three backward, a Linear with
-// its bias and ReLU is one kernel, log-softmax + NLL is one kernel.
+// the design goal is FEW launches, not MFMA tiling.  A training step of Net is 12 launches: conv + bias + 2x2 max-pool
+// + ReLU (+ channel dropout drawn in line from the counter hash) forward x2, Linear + bias + ReLU + element dropout,
+// Linear + log-softmax, NLL; backward: NLL, (log-softmax + Linear) dx|dw in one role-split launch, Linear dx|dw,
+// conv2 dx|dw, conv1 dw; step counter; fused SGD.  Dropout masks are never stored: forward draws them from
+// (seed, step, element), backward only needs "output > 0" and the constant 1/(1-p).  Weight gradients are ADDED into
+// whatever the caller passes (the flat gradient buffer when a sink is installed): no ATen add or fill kernels.
 // (Reference ops: multinode-DP/multinodeDP.py:88-95, multinode-MP/multinodeMP.py:84-100.)
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
 namespace dpa {
 namespace {
+
+struct DropArg { float p; uint64_t seed; uint64_t offset; const int64_t* step; };   // p == 0: no dropout
 
 constexpr int KS = 5;  // 5x5 filters, stride 1, no padding (DP.py:82-83)
 
@@ -17,9 +23,11 @@ constexpr int KS = 5;  // 5x5 filters, stride 1, no padding (DP.py:82-83)
 __global__ __launch_bounds__(256) void conv5_pool_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                   const float* __restrict__ b, float* __restrict__ y,
                                                                   uint8_t* __restrict__ idx, int N, int Cin, int H, int W,
-                                                                  int Cout, const float* __restrict__ drop) {
+                                                                  int Cout, DropArg d) {
     const int PH = (H - KS + 1) / 2, PW = (W - KS + 1) / 2;
     const long total = (long)N * Cout * PH * PW;
+    const uint64_t doff = d.offset + (d.step != nullptr ? (uint64_t)d.step[0] * 2000003ull : 0ull);
+    const float keep_scale = d.p > 0.f ? 1.f / (1.f - d.p) : 1.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         int pw = (int)(i % PW); long t = i / PW;
         int ph = (int)(t % PH); t /= PH;
@@ -47,52 +55,66 @@ __global__ __launch_bounds__(256) void conv5_pool_relu_fwd_kernel(const float* _
         if (a10 > best) { best = a10; bi = 2; }
         if (a11 > best) { best = a11; bi = 3; }
         best = fmaxf(best + b[co], 0.f);
-        if (drop != nullptr) best *= drop[n * Cout + co];
+        if (d.p > 0.f) best *= dropout_keep(d.seed, doff, (uint64_t)(n * Cout + co), d.p, keep_scale);   // Dropout2d: per (sample, channel)
         y[i] = best;
         idx[i] = (uint8_t)bi;
     }
 }
 
 // gradient w.r.t. the conv output at the arg-max position of pooled cell i
-__device__ __forceinline__ float pooled_grad(const float* dy, const float* y, const float* drop, long i, int nc) {
-    float g = y[i] > 0.f ? dy[i] : 0.f;
-    if (drop != nullptr) g *= drop[nc];
-    return g;
+// (a dropped channel has y == 0, a kept one was scaled by 1/(1-p) = gscale: no mask needed in backward)
+__device__ __forceinline__ float pooled_grad(const float* dy, const float* y, float gscale, long i) {
+    return y[i] > 0.f ? dy[i] * gscale : 0.f;
 }
 
 // dw: blockIdx.x = (co, ci), blockIdx.y = slice of the (n, ph, pw) cells; 25 accumulators per thread, block
 // reduction, then one atomic per filter tap into the zero-initialised dw / db (a 10-filter layer would
 // otherwise run on 10 workgroups of a 256-CU chip)
-__global__ __launch_bounds__(256) void conv5_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                       const float* __restrict__ y, const uint8_t* __restrict__ idx,
-                                                       float* __restrict__ dw, float* __restrict__ db, int N, int Cin,
-                                                       int H, int W, int Cout, const float* __restrict__ drop) {
+__device__ __forceinline__ void conv5_dw_body(int bx, int by, int ny, const float* __restrict__ x, const float* __restrict__ dy,
+                                              const float* __restrict__ y, const uint8_t* __restrict__ idx,
+                                              float* __restrict__ dw, float* __restrict__ db, int N, int Cin,
+                                              int H, int W, int Cout, float gscale, float (*red)[KS * KS + 1]) {
     const int PH = (H - KS + 1) / 2, PW = (W - KS + 1) / 2;
-    const int co = blockIdx.x / Cin, ci = blockIdx.x % Cin;
+    const int co = bx / Cin, ci = bx % Cin;
     float acc[KS * KS];
 #pragma unroll
     for (int k = 0; k < KS * KS; ++k) acc[k] = 0.f;
     float bsum = 0.f;
     const int cells = N * PH * PW;
-    const int per = (cells + gridDim.y - 1) / gridDim.y;
-    const int c0 = blockIdx.y * per, c1 = min(cells, c0 + per);
-    for (int c = c0 + threadIdx.x; c < c1; c += 256) {
-        const int pw = c % PW; int t = c / PW; const int ph = t % PH; const int n = t / PH;
-        const long i = (((long)n * Cout + co) * PH + ph) * PW + pw;
-        float g = dy[i];
-        if (drop != nullptr) { const float dm = drop[n * Cout + co]; g = (y[i] > 0.f) ? g * dm : 0.f; }
-        else g = (y[i] > 0.f) ? g : 0.f;
-        if (g == 0.f) continue;
-        const int bi = idx[i];
-        const int oh = ph * 2 + (bi >> 1), ow = pw * 2 + (bi & 1);
-        const float* xp = x + (((long)n * Cin + ci) * H + oh) * W + ow;
-        bsum += g;
+    const int per = (cells + ny - 1) / ny;
+    const int c0 = by * per, c1 = min(cells, c0 + per);
+    // Latency-bound: a cell is a three-deep dependent chain (dy, y, idx -> patch address -> 25 patch loads).  Four cells
+    // go through it together - 12 independent loads, then 100 - and a cell without gradient (ReLU / dropout / past the
+    // end) multiplies a valid patch by zero instead of branching around its loads.
+    for (int cb = c0 + threadIdx.x; cb < c1; cb += 256 * 4) {
+        float g[4]; const float* xp[4];
 #pragma unroll
-        for (int r = 0; r < KS; ++r)
+        for (int u = 0; u < 4; ++u) {
+            const int c = cb + 256 * u;
+            const bool ok = c < c1;
+            const int cc = ok ? c : c0;
+            const int pw = cc % PW; int t = cc / PW; const int ph = t % PH; const int n = t / PH;
+            const long i = (((long)n * Cout + co) * PH + ph) * PW + pw;
+            const float gv = pooled_grad(dy, y, gscale, i);
+            const int bi = idx[i];
+            g[u] = ok ? gv : 0.f;
+            const int oh = ph * 2 + (bi >> 1), ow = pw * 2 + (bi & 1);
+            xp[u] = x + (((long)n * Cin + ci) * H + oh) * W + ow;
+        }
+        float patch[4][KS * KS];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) acc[r * KS + s] += g * xp[r * W + s];
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < KS; ++r)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) patch[u][r * KS + s] = xp[u][r * W + s];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bsum += g[u];
+#pragma unroll
+            for (int k = 0; k < KS * KS; ++k) acc[k] += g[u] * patch[u][k];
+        }
     }
-    __shared__ float red[4][KS * KS + 1];
 #pragma unroll
     for (int k = 0; k < KS * KS; ++k) {
         const float v = wave_reduce_sum(acc[k]);
@@ -109,6 +131,14 @@ __global__ __launch_bounds__(256) void conv5_dw_kernel(const float* __restrict__
     if (threadIdx.x == 0 && ci == 0) atomicAdd(db + co, red[0][KS * KS] + red[1][KS * KS] + red[2][KS * KS] + red[3][KS * KS]);
 }
 
+__global__ __launch_bounds__(256) void conv5_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       const float* __restrict__ y, const uint8_t* __restrict__ idx,
+                                                       float* __restrict__ dw, float* __restrict__ db, int N, int Cin,
+                                                       int H, int W, int Cout, float gscale) {
+    __shared__ float red[4][KS * KS + 1];
+    conv5_dw_body(blockIdx.x, blockIdx.y, gridDim.y, x, dy, y, idx, dw, db, N, Cin, H, W, Cout, gscale, red);
+}
+
 // dx, LDS-tiled, shapes fixed at compile time (the reference's conv2: 10 -> 20 channels on 12x12): one
 // workgroup per sample.  The sample's conv-output gradient is scattered into a ZERO-PADDED dense
 // [Cout][OH+8][OW+8] LDS image (non-zero only at the pooling arg-max positions; the padding makes every
@@ -116,63 +146,93 @@ __global__ __launch_bounds__(256) void conv5_dw_kernel(const float* __restrict__
 // each thread produces one input ROW (ci, h, 0..W-1) in registers: per (co, r) it reads one padded
 // gradient row (4 x ds_read_b128) and five taps for 5*W FMAs of straight-line code.
 template <int CIN, int COUT, int HH, int WW>
-__global__ __launch_bounds__(256) void conv5_dx_tiled_kernel(const float* __restrict__ w, const float* __restrict__ dy,
-                                                             const float* __restrict__ y, const uint8_t* __restrict__ idx,
-                                                             float* __restrict__ dx, const float* __restrict__ drop) {
-    constexpr int OH = HH - KS + 1, OW = WW - KS + 1, PH = OH / 2, PW = OW / 2;
-    constexpr int GH = OH + 2 * (KS - 1), GW = (OW + 2 * (KS - 1) + 3) / 4 * 4;    // padded image, rows 16-byte multiples
+struct Conv5DxTile {
+    static constexpr int OH = HH - KS + 1, OW = WW - KS + 1, PH = OH / 2, PW = OW / 2;
+    static constexpr int GH = OH + 2 * (KS - 1), GW = (OW + 2 * (KS - 1) + 3) / 4 * 4;    // padded image, rows 16-byte multiples
+    static constexpr int G_FLOATS = COUT * GH * GW, W_FLOATS = COUT * CIN * KS * KS, ROWS = CIN * HH;
     static_assert(GW >= WW + KS - 1, "padded row must cover every tap of every output column");
-    __shared__ __attribute__((aligned(16))) float G[COUT * GH * GW];
-    __shared__ __attribute__((aligned(16))) float Wl[COUT * CIN * KS * KS];
-    const int n = blockIdx.x;
-    for (int i = threadIdx.x; i < COUT * GH * GW; i += 256) G[i] = 0.f;
-    for (int i = threadIdx.x; i < COUT * CIN * KS * KS; i += 256) Wl[i] = w[i];
-    __syncthreads();
-    for (int i = threadIdx.x; i < COUT * PH * PW; i += 256) {
-        const int pw = i % PW; int t = i / PW; const int ph = t % PH; const int co = t / PH;
-        const long o = (long)n * COUT * PH * PW + i;
-        float g = y[o] > 0.f ? dy[o] : 0.f;
-        if (drop != nullptr) g *= drop[n * COUT + co];
-        const int bi = idx[o];
-        G[(co * GH + ph * 2 + (bi >> 1) + KS - 1) * GW + pw * 2 + (bi & 1) + KS - 1] = g;
-    }
-    __syncthreads();
-    const int row = threadIdx.x;
-    if (row >= CIN * HH) return;
-    const int ci = row / HH, h = row - ci * HH;
-    float acc[WW];
+    static_assert(2 * ROWS <= 256 && COUT % 2 == 0, "two thread groups, each half of the filters");
+    static_assert(ROWS * WW <= G_FLOATS, "the partial sums of the second group reuse the gradient image");
+
+    // Threads [0, ROWS) take filters [0, COUT/2), threads [ROWS, 2 ROWS) the other half of the same input row (the
+    // layer has 120 rows per sample: one group would leave half the workgroup idle on a latency-bound loop); the
+    // second group's partial row goes through LDS.
+    static __device__ __forceinline__ void run(int n, const float* __restrict__ w, const float* __restrict__ dy,
+                                               const float* __restrict__ y, const uint8_t* __restrict__ idx,
+                                               float* __restrict__ dx, float gscale, float* G, float* Wl) {
+        for (int i = threadIdx.x; i < G_FLOATS; i += 256) G[i] = 0.f;
+        for (int i = threadIdx.x; i < W_FLOATS; i += 256) Wl[i] = w[i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < COUT * PH * PW; i += 256) {
+            const int pw = i % PW; int t = i / PW; const int ph = t % PH; const int co = t / PH;
+            const long o = (long)n * COUT * PH * PW + i;
+            const int bi = idx[o];
+            G[(co * GH + ph * 2 + (bi >> 1) + KS - 1) * GW + pw * 2 + (bi & 1) + KS - 1] = pooled_grad(dy, y, gscale, o);
+        }
+        __syncthreads();
+        const int half = threadIdx.x >= ROWS ? 1 : 0, row = threadIdx.x - half * ROWS;
+        const bool active = threadIdx.x < 2 * ROWS;
+        const int ci = row / HH, h = row - ci * HH;
+        float acc[WW];
 #pragma unroll
-    for (int v = 0; v < WW; ++v) acc[v] = 0.f;
-    for (int co = 0; co < COUT; ++co) {
+        for (int v = 0; v < WW; ++v) acc[v] = 0.f;
+        if (active) {
+            for (int co = half * (COUT / 2); co < (half + 1) * (COUT / 2); ++co) {
 #pragma unroll
-        for (int r = 0; r < KS; ++r) {
-            // dx[h][v] += sum_s G[h - r][v - s] * w[r][s];  padded coordinates: row h - r + 4, column v - s + 4
-            const float4* gp4 = (const float4*)(G + (co * GH + h - r + KS - 1) * GW);
-            float gr[GW];
+                for (int r = 0; r < KS; ++r) {
+                    // dx[h][v] += sum_s G[h - r][v - s] * w[r][s];  padded coordinates: row h - r + 4, column v - s + 4
+                    const float4* gp4 = (const float4*)(G + (co * GH + h - r + KS - 1) * GW);
+                    float gr[GW];
 #pragma unroll
-            for (int q = 0; q < GW / 4; ++q) {
-                const float4 t4 = gp4[q];
-                gr[4 * q] = t4.x; gr[4 * q + 1] = t4.y; gr[4 * q + 2] = t4.z; gr[4 * q + 3] = t4.w;
-            }
-            const float* wp = Wl + ((co * CIN + ci) * KS + r) * KS;
+                    for (int q = 0; q < GW / 4; ++q) {
+                        const float4 t4 = gp4[q];
+                        gr[4 * q] = t4.x; gr[4 * q + 1] = t4.y; gr[4 * q + 2] = t4.z; gr[4 * q + 3] = t4.w;
+                    }
+                    const float* wp = Wl + ((co * CIN + ci) * KS + r) * KS;
 #pragma unroll
-            for (int sft = 0; sft < KS; ++sft) {
-                const float wv = wp[sft];
+                    for (int sft = 0; sft < KS; ++sft) {
+                        const float wv = wp[sft];
 #pragma unroll
-                for (int v = 0; v < WW; ++v) acc[v] += gr[v - sft + KS - 1] * wv;
+                        for (int v = 0; v < WW; ++v) acc[v] += gr[v - sft + KS - 1] * wv;
+                    }
+                }
             }
         }
-    }
-    float* dst = dx + (((long)n * CIN + ci) * HH + h) * WW;
+        __syncthreads();                                   // everyone is done reading G: its front becomes the exchange buffer
+        if (active && half == 1) {
 #pragma unroll
-    for (int v = 0; v < WW; ++v) dst[v] = acc[v];
+            for (int v = 0; v < WW; ++v) G[row * WW + v] = acc[v];
+        }
+        __syncthreads();
+        if (active && half == 0) {
+            float* dst = dx + (((long)n * CIN + ci) * HH + h) * WW;
+#pragma unroll
+            for (int v = 0; v < WW; ++v) dst[v] = acc[v] + G[row * WW + v];
+        }
+    }
+};
+
+// conv backward of the reference's conv2 in ONE launch: workgroups [0, N) produce dx (one sample each), the rest dw / db
+// (filter pair x slice of the cells).  The two halves are independent; one launch instead of two, running side by side.
+template <int CIN, int COUT, int HH, int WW>
+__global__ __launch_bounds__(256) void conv5_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ dy, const float* __restrict__ y,
+                                                              const uint8_t* __restrict__ idx, float* __restrict__ dx,
+                                                              float* __restrict__ dw, float* __restrict__ db, int N, float gscale,
+                                                              int split) {
+    using T = Conv5DxTile<CIN, COUT, HH, WW>;
+    __shared__ __attribute__((aligned(16))) float G[T::G_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Wl[T::W_FLOATS];
+    if ((int)blockIdx.x < N) { T::run(blockIdx.x, w, dy, y, idx, dx, gscale, G, Wl); return; }
+    const int b = blockIdx.x - N;
+    conv5_dw_body(b / split, b % split, split, x, dy, y, idx, dw, db, N, CIN, HH, WW, COUT, gscale, (float (*)[KS * KS + 1])G);
 }
 
 // dx: one thread per input element; walks the (co, r, s) taps and keeps those that hit an arg-max
 __global__ __launch_bounds__(256) void conv5_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
                                                        const float* __restrict__ y, const uint8_t* __restrict__ idx,
                                                        float* __restrict__ dx, int N, int Cin, int H, int W, int Cout,
-                                                       const float* __restrict__ drop) {
+                                                       float gscale) {
     const int OH = H - KS + 1, OW = W - KS + 1, PH = OH / 2, PW = OW / 2;
     const long total = (long)N * Cin * H * W;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -181,8 +241,6 @@ __global__ __launch_bounds__(256) void conv5_dx_kernel(const float* __restrict__
         int ci = (int)(t % Cin); int n = (int)(t / Cin);
         float acc = 0.f;
         for (int co = 0; co < Cout; ++co) {
-            const float dm = drop != nullptr ? drop[n * Cout + co] : 1.f;
-            if (dm == 0.f) continue;
             const float* wp = w + ((long)co * Cin + ci) * KS * KS;
             const long obase = ((long)n * Cout + co) * PH * PW;
 #pragma unroll
@@ -194,7 +252,7 @@ __global__ __launch_bounds__(256) void conv5_dx_kernel(const float* __restrict__
                     const int ow = wv - s;
                     if (ow < 0 || ow >= PW * 2) continue;
                     const long o = obase + (oh >> 1) * PW + (ow >> 1);
-                    if (idx[o] == ((oh & 1) * 2 + (ow & 1)) && y[o] > 0.f) acc += dy[o] * dm * wp[r * KS + s];
+                    if (idx[o] == ((oh & 1) * 2 + (ow & 1)) && y[o] > 0.f) acc += dy[o] * gscale * wp[r * KS + s];
                 }
             }
         }
@@ -202,73 +260,161 @@ __global__ __launch_bounds__(256) void conv5_dx_kernel(const float* __restrict__
     }
 }
 
-// y = act(x @ w^T + b): one thread per (row, out)
+// y = dropout(act(x @ w^T + b)): 8 lanes per (row, out) split the K loop (a 320-long serial FMA chain per thread made the
+// 128 x 50 layer run 12 us on 25 workgroups), folded with three lane shuffles
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ b, float* __restrict__ y, int rows,
-                                                         int in, int out, int relu) {
+                                                         int in, int out, int relu, DropArg d) {
     const long total = (long)rows * out;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int sub = threadIdx.x & 7;
+    const uint64_t doff = d.offset + (d.step != nullptr ? (uint64_t)d.step[0] * 2000003ull : 0ull);
+    const float keep_scale = d.p > 0.f ? 1.f / (1.f - d.p) : 1.f;
+    const long groups = ((long)gridDim.x * 256) >> 3;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) >> 3; i < total; i += groups) {   // the 8 lanes of a group share i
         const int o = (int)(i % out); const long r = i / out;
         const float* xp = x + r * in; const float* wp = w + (long)o * in;
-        float acc = b != nullptr ? b[o] : 0.f;
-        int k = 0;
-        if (((in & 3) == 0)) {
-            for (; k < in; k += 4) {
+        float acc = 0.f;
+        if ((in & 3) == 0) {
+            for (int k = sub * 4; k < in; k += 32) {
                 const float4 a = *(const float4*)(xp + k), c = *(const float4*)(wp + k);
                 acc += a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
             }
         } else {
-            for (; k < in; ++k) acc += xp[k] * wp[k];
+            for (int k = sub; k < in; k += 8) acc += xp[k] * wp[k];
         }
-        y[i] = relu ? fmaxf(acc, 0.f) : acc;
+        acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+        if (sub == 0) {
+            float v = acc + (b != nullptr ? b[o] : 0.f);
+            if (relu) v = fmaxf(v, 0.f);
+            if (d.p > 0.f) v *= dropout_keep(d.seed, doff, (uint64_t)i, d.p, keep_scale);
+            y[i] = v;
+        }
     }
 }
 
-// dx[r][k] = sum_o g[r][o] * w[o][k],  g = dy * (relu ? y>0 : 1)
-__global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict__ w, const float* __restrict__ y,
-                                                        const float* __restrict__ dy, float* __restrict__ dx, int rows,
-                                                        int in, int out, int relu) {
-    const long total = (long)rows * in;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int k = (int)(i % in); const long r = i / in;
-        float acc = 0.f;
-        for (int o = 0; o < out; ++o) {
-            float g = dy[r * out + o];
-            if (relu && !(y[r * out + o] > 0.f)) g = 0.f;
-            acc += g * w[(long)o * in + k];
-        }
-        dx[i] = acc;
+// logp = log_softmax(x @ w^T + b) for a narrow output layer (out <= 64): one wave per row, lane o owns class o
+__global__ __launch_bounds__(256) void linear_lsm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, float* __restrict__ logp, int rows,
+                                                             int in, int out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xp = x + (long)row * in;
+    float v = -INFINITY;
+    if (lane < out) {
+        const float* wp = w + (long)lane * in;
+        float acc = b != nullptr ? b[lane] : 0.f;
+        for (int k = 0; k < in; ++k) acc += xp[k] * wp[k];
+        v = acc;
     }
+    const float m = wave_reduce_max(v);
+    const float s = wave_reduce_sum(lane < out ? __expf(v - m) : 0.f);
+    if (lane < out) logp[(long)row * out + lane] = v - m - __logf(s);
 }
 
-// dw[o][k] = sum_r g[r][o] * x[r][k] ; db[o] = sum_r g[r][o].  Block = (o, 64-wide k tile); the 4 waves take
-// interleaved rows (8 independent loads in flight per thread - the loop is latency-bound, not
-// bandwidth-bound) and are folded through LDS.  x rows are read coalesced over k; g[r][o] is a broadcast.
-__global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                        const float* __restrict__ dy, float* __restrict__ dw,
-                                                        float* __restrict__ db, int rows, int in, int out, int relu) {
+// Upstream gradient of a Linear's pre-activation, element (r, o):
+//   plain:  g = dy * (relu ? (y > 0) * gscale : 1)          (y = the layer's stored output; gscale = 1/(1-p) of a dropout behind it)
+//   lsm:    g = dy - exp(y) * sum_c dy[r][c]                 (y = log-probabilities: log-softmax backward in line)
+// These loops are LATENCY-bound (a few hundred loads per thread, one wave per SIMD): every helper below issues its loads
+// in independent batches of 8 before anything consumes them - a runtime-trip-count loop with one load per iteration
+// costs one L2 round trip per iteration (measured: 40 us for the 128 x 10 head, 18 us for the 128 x 50 layer).
+// NARROW (out <= 16, the classifier head): one predicated batch of 16, no loop - every load of a thread's work item is
+// then independent of every other and the whole item costs ONE memory round trip (data written by the previous kernel
+// comes from another XCD's L2 through the fabric: ~2 us per dependent step, which is what these kernels are made of)
+template <bool NARROW>
+__device__ __forceinline__ float lin_rowsum(const float* __restrict__ dy, long r, int out) {
+    float s = 0.f;
+    if (NARROW) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = u < out ? dy[r * out + u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+        return s;
+    }
+    for (int c0 = 0; c0 < out; c0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = c0 + u < out ? dy[r * out + c0 + u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    return s;
+}
+__device__ __forceinline__ float lin_g1(float dyv, float yv, int relu, float gscale, int lsm, float rowsum) {
+    if (lsm) return dyv - __expf(yv) * rowsum;
+    if (relu) return yv > 0.f ? dyv * gscale : 0.f;
+    return dyv;
+}
+
+// Linear backward in ONE launch.  Workgroups [0, dx_blocks): dx[r][k] = sum_o g[r][o] * w[o][k], one thread per element.
+// The rest: dw[o][k] (+)= sum_r g[r][o] * x[r][k], db[o] (+)= sum_r g[r][o]; block = (o, 64-wide k tile); the 4 waves take
+// interleaved rows, folded through LDS.
+template <bool NARROW>
+__global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ y, const float* __restrict__ dy,
+                                                         float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
+                                                         int rows, int in, int out, int relu, float gscale, int lsm,
+                                                         int accumulate, int dx_blocks) {
+    if ((int)blockIdx.x < dx_blocks) {
+        const long total = (long)rows * in;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)dx_blocks * 256) {
+            const int k = (int)(i % in); const long r = i / in;
+            const float rs = lsm ? lin_rowsum<NARROW>(dy, r, out) : 0.f;
+            float acc = 0.f;
+            if (NARROW) {
+                float dv[16], yv[16], wv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const bool ok = u < out;
+                    const long e = r * out + (ok ? u : 0);
+                    dv[u] = ok ? dy[e] : 0.f;
+                    yv[u] = (relu || lsm) ? y[e] : 1.f;
+                    wv[u] = ok ? w[(long)u * in + k] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc += (u < out ? lin_g1(dv[u], yv[u], relu, gscale, lsm, rs) : 0.f) * wv[u];
+                dx[i] = acc;
+                continue;
+            }
+            for (int o0 = 0; o0 < out; o0 += 8) {
+                float dv[8], yv[8], wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool ok = o0 + u < out;
+                    const long e = r * out + (ok ? o0 + u : 0);
+                    dv[u] = ok ? dy[e] : 0.f;
+                    yv[u] = (relu || lsm) ? y[e] : 1.f;
+                    wv[u] = ok ? w[(long)(o0 + u) * in + k] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += (o0 + u < out ? lin_g1(dv[u], yv[u], relu, gscale, lsm, rs) : 0.f) * wv[u];
+            }
+            dx[i] = acc;
+        }
+        return;
+    }
+    const int bid = blockIdx.x - dx_blocks;
     const int ktiles = (in + 63) / 64;
-    const int o = blockIdx.x / ktiles, k = (blockIdx.x % ktiles) * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int o = bid / ktiles, k = (bid % ktiles) * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
     const bool kok = k < in;
     float acc = 0.f, bs = 0.f;
-    int r = rg;
-    for (; r + 28 < rows; r += 32) {
-        float g[8], xv[8];
+    for (int r = rg; r < rows; r += 32) {
+        float dv[8], yv[8], xv[8], rs[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const long rr = r + 4 * u;
-            g[u] = dy[rr * out + o];
-            if (relu && !(y[rr * out + o] > 0.f)) g[u] = 0.f;
-            xv[u] = kok ? x[rr * in + k] : 0.f;
+            const bool ok = rr < rows;
+            const long e = (ok ? rr : 0) * out + o;
+            dv[u] = ok ? dy[e] : 0.f;
+            yv[u] = (relu || lsm) ? y[e] : 1.f;
+            xv[u] = (ok && kok) ? x[rr * in + k] : 0.f;
+            rs[u] = (lsm && ok) ? lin_rowsum<NARROW>(dy, rr, out) : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { acc += g[u] * xv[u]; bs += g[u]; }
-    }
-    for (; r < rows; r += 4) {
-        float g = dy[(long)r * out + o];
-        if (relu && !(y[(long)r * out + o] > 0.f)) g = 0.f;
-        acc += g * (kok ? x[(long)r * in + k] : 0.f);
-        bs += g;
+        for (int u = 0; u < 8; ++u) {
+            const float g = r + 4 * u < rows ? lin_g1(dv[u], yv[u], relu, gscale, lsm, rs[u]) : 0.f;
+            acc += g * xv[u]; bs += g;
+        }
     }
     __shared__ float red[2][4][64];
     red[0][rg][threadIdx.x & 63] = acc;
@@ -276,8 +422,15 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
     __syncthreads();
     if (rg == 0) {
         const int l = threadIdx.x;
-        if (kok) dw[(long)o * in + k] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
-        if (l == 0 && blockIdx.x % ktiles == 0 && db != nullptr) db[o] = red[1][0][0] + red[1][1][0] + red[1][2][0] + red[1][3][0];
+        if (kok) {
+            const float v = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+            float* dst = dw + (long)o * in + k;
+            *dst = accumulate ? *dst + v : v;              // one writer per element
+        }
+        if (l == 0 && bid % ktiles == 0 && db != nullptr) {
+            const float v = red[1][0][0] + red[1][1][0] + red[1][2][0] + red[1][3][0];
+            db[o] = accumulate ? db[o] + v : v;
+        }
     }
 }
 
@@ -333,40 +486,56 @@ inline int grid_for(long n) { long b = (n + 255) / 256; if (b > 2048) b = 2048; 
 }  // namespace
 
 void conv5_pool_relu_fwd(const float* x, const float* w, const float* b, float* y, uint8_t* idx,
-                         int N, int Cin, int H, int W, int Cout, const float* drop_mask, hipStream_t st) {
+                         int N, int Cin, int H, int W, int Cout, float drop_p, uint64_t seed, uint64_t offset,
+                         const int64_t* step, hipStream_t st) {
     const int PH = (H - KS + 1) / 2, PW = (W - KS + 1) / 2;
     hipLaunchKernelGGL(conv5_pool_relu_fwd_kernel, dim3(grid_for((long)N * Cout * PH * PW)), dim3(256), 0, st, x, w, b, y, idx,
-                       N, Cin, H, W, Cout, drop_mask);
+                       N, Cin, H, W, Cout, DropArg{drop_p, seed, offset, step});
 }
 
 void conv5_pool_relu_bwd(const float* x, const float* w, const float* dy, const float* y, const uint8_t* idx,
                          float* dx, float* dw, float* db, int N, int Cin, int H, int W, int Cout,
-                         const float* drop_mask, hipStream_t st) {
-    // dw / db are accumulated with atomics: the caller passes them zero-initialised
+                         float gscale, hipStream_t st) {
+    // dw / db are ADDED to with atomics (pixel split): zero-initialised by the caller, or the flat gradient buffer
     const int PH = (H - KS + 1) / 2, PW = (W - KS + 1) / 2;
     const int cells = N * PH * PW;
+    // every split adds one more same-address float atomic per filter tap (they serialise in L2: conv1's 10 filters
+    // at 51 splits spent 10 of its 16 us there), so the cells are cut only until each thread has ~4 of them (one batch of the loop below)
+    static const int cells_per_thread = [] { const char* e = getenv("DPA_CONV5_CPT"); return e ? atoi(e) : 4; }();
     int split = 512 / (Cout * Cin);
-    if (split > (cells + 255) / 256) split = (cells + 255) / 256;
-    if (split < 1) split = 1;
-    hipLaunchKernelGGL(conv5_dw_kernel, dim3(Cout * Cin, split), dim3(256), 0, st, x, dy, y, idx, dw, db, N, Cin, H, W, Cout, drop_mask);
-    if (dx != nullptr) {
-        if (Cin == 10 && Cout == 20 && H == 12 && W == 12)   // the reference's conv2 (DP.py:83)
-            hipLaunchKernelGGL((conv5_dx_tiled_kernel<10, 20, 12, 12>), dim3(N), dim3(256), 0, st, w, dy, y, idx, dx, drop_mask);
-        else
-            hipLaunchKernelGGL(conv5_dx_kernel, dim3(grid_for((long)N * Cin * H * W)), dim3(256), 0, st, w, dy, y, idx, dx, N, Cin,
-                               H, W, Cout, drop_mask);
+    if (split > (cells + 256 * cells_per_thread - 1) / (256 * cells_per_thread)) split = (cells + 256 * cells_per_thread - 1) / (256 * cells_per_thread);
+    if (split < 1 || deterministic()) split = 1;            // one writer per filter tap (runtime.hip)
+    if (dx != nullptr && Cin == 10 && Cout == 20 && H == 12 && W == 12) {   // the reference's conv2 (DP.py:83): dx | dw in one launch
+        hipLaunchKernelGGL((conv5_bwd_fused_kernel<10, 20, 12, 12>), dim3(N + Cout * Cin * split), dim3(256), 0, st, x, w, dy, y,
+                           idx, dx, dw, db, N, gscale, split);
+        return;
     }
+    hipLaunchKernelGGL(conv5_dw_kernel, dim3(Cout * Cin, split), dim3(256), 0, st, x, dy, y, idx, dw, db, N, Cin, H, W, Cout, gscale);
+    if (dx != nullptr)
+        hipLaunchKernelGGL(conv5_dx_kernel, dim3(grid_for((long)N * Cin * H * W)), dim3(256), 0, st, w, dy, y, idx, dx, N, Cin,
+                           H, W, Cout, gscale);
 }
 
-void linear_f32_fwd(const float* x, const float* w, const float* b, float* y, int rows, int in, int out, int relu, hipStream_t st) {
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3(grid_for((long)rows * out)), dim3(256), 0, st, x, w, b, y, rows, in, out, relu);
+void linear_f32_fwd(const float* x, const float* w, const float* b, float* y, int rows, int in, int out, int relu,
+                    float drop_p, uint64_t seed, uint64_t offset, const int64_t* step, hipStream_t st) {
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3(grid_for((long)rows * out * 8)), dim3(256), 0, st, x, w, b, y, rows, in, out, relu,
+                       DropArg{drop_p, seed, offset, step});
+}
+
+void linear_lsm_fwd(const float* x, const float* w, const float* b, float* logp, int rows, int in, int out, hipStream_t st) {
+    hipLaunchKernelGGL(linear_lsm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, w, b, logp, rows, in, out);
 }
 
 void linear_f32_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* db,
-                    int rows, int in, int out, int relu, hipStream_t st) {
-    if (dx != nullptr)
-        hipLaunchKernelGGL(linear_dx_kernel, dim3(grid_for((long)rows * in)), dim3(256), 0, st, w, y, dy, dx, rows, in, out, relu);
-    hipLaunchKernelGGL(linear_dw_kernel, dim3((unsigned)(out * ((in + 63) / 64))), dim3(256), 0, st, x, y, dy, dw, db, rows, in, out, relu);
+                    int rows, int in, int out, int relu, float gscale, int lsm, int accumulate, hipStream_t st) {
+    const int dxb = dx != nullptr ? grid_for((long)rows * in) : 0;
+    const int dwb = out * ((in + 63) / 64);
+    if (out <= 16)
+        hipLaunchKernelGGL(linear_bwd_kernel<true>, dim3((unsigned)(dxb + dwb)), dim3(256), 0, st, x, w, y, dy, dx, dw, db, rows, in,
+                           out, relu, gscale, lsm, accumulate, dxb);
+    else
+        hipLaunchKernelGGL(linear_bwd_kernel<false>, dim3((unsigned)(dxb + dwb)), dim3(256), 0, st, x, w, y, dy, dx, dw, db, rows, in,
+                           out, relu, gscale, lsm, accumulate, dxb);
 }
 
 void log_softmax_fwd(const float* x, float* y, int rows, int V, hipStream_t st) {

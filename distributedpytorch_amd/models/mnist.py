@@ -55,23 +55,24 @@ class Net(nn.Module):
         self.fc2 = nn.Linear(50, 10)
         self._drop = _DropState(seed)
 
+    def _drop_arg(self, p: float, layer: int):
+        if not self.training or p <= 0:
+            return None
+        return (p, self._drop.seed, self._drop.next(layer), self._drop.dev_step)
+
     def features(self, x: torch.Tensor) -> torch.Tensor:
         x = ops.conv5_pool_relu(x, self.conv1.weight, self.conv1.bias)
-        mask = None
-        if self.training and self.conv2_drop.p > 0:
-            mask = ops.channel_dropout_mask(x.shape[0], 20, self.conv2_drop.p, x, self._drop.seed,
-                                            self._drop.next(0), self._drop.dev_step)
-        x = ops.conv5_pool_relu(x, self.conv2.weight, self.conv2.bias, mask)
+        x = ops.conv5_pool_relu(x, self.conv2.weight, self.conv2.bias, self._drop_arg(self.conv2_drop.p, 0))
         return x.reshape(-1, 320)
 
+    def hidden(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.linear_f32(self.features(x), self.fc1.weight, self.fc1.bias, relu=True, drop=self._drop_arg(0.5, 7))
+
     def logits(self, x: torch.Tensor) -> torch.Tensor:
-        x = self.features(x)
-        x = ops.linear_f32(x, self.fc1.weight, self.fc1.bias, relu=True)
-        x = ops.dropout(x, 0.5, self.training, self._drop.seed, self._drop.next(7), self._drop.dev_step)
-        return ops.linear_f32(x, self.fc2.weight, self.fc2.bias)
+        return ops.linear_f32(self.hidden(x), self.fc2.weight, self.fc2.bias)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return ops.log_softmax(self.logits(x))
+        return ops.linear_log_softmax(self.hidden(x), self.fc2.weight, self.fc2.bias)
 
 
 class Net1(nn.Module):
@@ -98,8 +99,7 @@ class Net2(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = ops.linear_f32(x, self.fc1.weight, self.fc1.bias, relu=True)
-        x = ops.linear_f32(x, self.fc2.weight, self.fc2.bias)
-        return ops.log_softmax(x)
+        return ops.linear_log_softmax(x, self.fc2.weight, self.fc2.bias)
 
 
 def nll_loss(log_probs: torch.Tensor, target: torch.Tensor) -> torch.Tensor:

@@ -1,5 +1,8 @@
 """fp32 NCHW ops of the reference's MNIST networks, fused for launch count.
 
+Every weight gradient is ADDED into the parallel engine's flat buffer when a gradient sink covers the parameter
+(ops/sink.py) - no per-parameter ATen add / fill kernels - and dropout masks are drawn inside the kernels.
+
 ``conv5_pool_relu``  = ``relu(max_pool2d(dropout2d?(conv2d(x, w, b)), 2))``
 (reference multinode-DP/multinodeDP.py:89-90; pool and ReLU commute because both are
 monotone, and channel dropout is a non-negative per-channel scale so it commutes
@@ -8,73 +11,121 @@ and ``nll_loss`` (DP.py:95,152).
 """
 from __future__ import annotations
 
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 import torch.nn.functional as F
 
 from . import _ext
+from . import sink as _sink
+
+
+# Dropout argument of the fused kernels: (p, seed, offset, step) - ``step`` an optional device int64 counter.  The mask
+# is drawn INSIDE the kernel from a counter hash of (seed, offset + step, element); backward needs no mask at all (a
+# dropped element has output 0, a kept one was scaled by the constant 1/(1-p)).
+Drop = Optional[Tuple[float, int, int, Optional[torch.Tensor]]]
+_NO_DROP = (0.0, 0, 0, None)
+
+
+def _sink_pair(w, b):
+    tw, tb = _sink.target(w), _sink.target(b)
+    return (tw, tb) if (tw is not None and tb is not None) else (None, None)
 
 
 class _Conv5PoolReluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, drop):
         C = _ext.load()
-        y, idx = C.conv5_pool_relu_fwd(x, w.detach(), b.detach(), drop)
-        ctx.save_for_backward(x, w, y, idx)
-        ctx.drop = drop
+        p, seed, offset, step = drop
+        y, idx = C.conv5_pool_relu_fwd(x, w.detach(), b.detach(), p, seed, offset, step)
+        ctx.save_for_backward(x, y, idx)
+        ctx.w, ctx.b = w, b                        # the Parameter objects themselves: the gradient sink hangs off them
+        ctx.gscale = 1.0 / (1.0 - p) if p > 0 else 1.0
         return y
 
     @staticmethod
     def backward(ctx, dy):
         C = _ext.load()
-        x, w, y, idx = ctx.saved_tensors
-        dx, dw, db = C.conv5_pool_relu_bwd(x, w.detach(), dy.contiguous(), y, idx, ctx.drop, ctx.needs_input_grad[0])
+        x, y, idx = ctx.saved_tensors
+        w, b = ctx.w, ctx.b
+        tw, tb = _sink_pair(w, b)
+        dx, dw, db = C.conv5_pool_relu_bwd(x, w.detach(), dy.contiguous(), y, idx, ctx.gscale, ctx.needs_input_grad[0], tw, tb)
+        if tw is not None:                         # added straight into the flat gradient buffer
+            _sink.ready(w); _sink.ready(b)
+            dw = db = None
         return (dx if ctx.needs_input_grad[0] else None), dw, db, None
 
 
 def channel_dropout_mask(n: int, c: int, p: float, like: torch.Tensor, seed: int, offset: int,
                          step: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``[n*c]`` mask of 0 or 1/(1-p): one Bernoulli per (sample, channel) = ``Dropout2d``.
-    ``step``: device int64 step counter added to the stream position (hipGraph-replay safe)."""
+    """``[n*c]`` mask of 0 or 1/(1-p): one Bernoulli per (sample, channel) = ``Dropout2d`` - what the fused conv kernel
+    draws in line on the GPU (same counter hash: ``dropout_mask`` reproduces it), a host generator on the CPU."""
     if like.is_cuda:
         return _ext.load().dropout_mask(n * c, p, seed, offset, like, step)
     g = torch.Generator().manual_seed(seed * 1000003 + offset)
     return (torch.rand(n * c, generator=g) >= p).float() / (1.0 - p)
 
 
-def conv5_pool_relu(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, drop_mask: Optional[torch.Tensor] = None):
-    """x ``[N,Cin,H,W]`` fp32, w ``[Cout,Cin,5,5]`` -> ``[N,Cout,(H-4)/2,(W-4)/2]``."""
+def conv5_pool_relu(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, drop: Drop = None):
+    """x ``[N,Cin,H,W]`` fp32, w ``[Cout,Cin,5,5]`` -> ``[N,Cout,(H-4)/2,(W-4)/2]``; ``drop``: channel dropout behind it."""
     if _ext.use_hip(x):
-        return _Conv5PoolReluFn.apply(x.contiguous(), w, b, drop_mask)
+        return _Conv5PoolReluFn.apply(x.contiguous(), w, b, drop if drop is not None else _NO_DROP)
     y = F.conv2d(x, w, b)
-    if drop_mask is not None:
-        y = y * drop_mask.view(y.shape[0], y.shape[1], 1, 1)
+    if drop is not None and drop[0] > 0:
+        mask = channel_dropout_mask(y.shape[0], y.shape[1], drop[0], y, drop[1], drop[2], drop[3])
+        y = y * mask.view(y.shape[0], y.shape[1], 1, 1)
     return F.relu(F.max_pool2d(y, 2))
 
 
 class _LinearF32Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, relu):
+    def forward(ctx, x, w, b, relu, drop, lsm):
         C = _ext.load()
-        y = C.linear_f32_fwd(x, w.detach(), b.detach(), relu)
-        ctx.save_for_backward(x, w, y)
-        ctx.relu = relu
+        p, seed, offset, step = drop
+        if lsm:
+            y = C.linear_log_softmax_fwd(x, w.detach(), b.detach())
+        else:
+            y = C.linear_f32_fwd(x, w.detach(), b.detach(), relu, p, seed, offset, step)
+        ctx.save_for_backward(x, y)
+        ctx.w, ctx.b = w, b
+        ctx.relu, ctx.lsm = relu, lsm
+        ctx.gscale = 1.0 / (1.0 - p) if p > 0 else 1.0
         return y
 
     @staticmethod
     def backward(ctx, dy):
         C = _ext.load()
-        x, w, y = ctx.saved_tensors
-        dx, dw, db = C.linear_f32_bwd(x, w.detach(), y, dy.contiguous(), ctx.relu, ctx.needs_input_grad[0])
-        return (dx if ctx.needs_input_grad[0] else None), dw, db, None
+        x, y = ctx.saved_tensors
+        w, b = ctx.w, ctx.b
+        tw, tb = _sink_pair(w, b)
+        # a dropout behind a ReLU-less layer would need its mask (0 outputs are not all drops): not a case these nets have
+        dx, dw, db = C.linear_f32_bwd(x, w.detach(), y, dy.contiguous(), ctx.relu, ctx.gscale, ctx.lsm, ctx.needs_input_grad[0], tw, tb)
+        if tw is not None:
+            _sink.ready(w); _sink.ready(b)
+            dw = db = None
+        return (dx if ctx.needs_input_grad[0] else None), dw, db, None, None, None
 
 
-def linear_f32(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, relu: bool = False) -> torch.Tensor:
+def linear_f32(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, relu: bool = False, drop: Drop = None) -> torch.Tensor:
+    """``dropout(relu?(x @ w^T + b))`` (reference DP.py:92-94) as one kernel; ``drop`` needs ``relu`` (see backward)."""
+    if drop is not None and drop[0] > 0 and not relu:
+        raise ValueError("linear_f32: fused dropout is implemented behind a ReLU only")
     if _ext.use_hip(x):
-        return _LinearF32Fn.apply(x.contiguous(), w, b, relu)
+        return _LinearF32Fn.apply(x.contiguous(), w, b, relu, drop if drop is not None else _NO_DROP, False)
     y = F.linear(x, w, b)
-    return F.relu(y) if relu else y
+    y = F.relu(y) if relu else y
+    if drop is not None and drop[0] > 0:
+        g = torch.Generator().manual_seed(drop[1] * 1000003 + drop[2])
+        y = y * ((torch.rand(y.numel(), generator=g) >= drop[0]).float().view(y.shape) / (1.0 - drop[0]))
+    return y
+
+
+def linear_log_softmax(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """``log_softmax(x @ w^T + b, dim=1)`` (reference DP.py:94-95) as one kernel forward; backward folds the
+    log-softmax gradient into the Linear's dx | dw launch."""
+    if _ext.use_hip(x) and w.shape[0] <= 64:
+        return _LinearF32Fn.apply(x.contiguous(), w, b, False, _NO_DROP, True)
+    return log_softmax(linear_f32(x, w, b))
 
 
 class _DropoutFn(torch.autograd.Function):
@@ -91,7 +142,7 @@ class _DropoutFn(torch.autograd.Function):
 
 def dropout(x: torch.Tensor, p: float, training: bool, seed: int, offset: int,
             step: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Element dropout (reference DP.py:93) with a counter-based mask generated on device."""
+    """Stand-alone element dropout (mask tensor + multiply): for callers outside the fused layers."""
     if not training or p == 0.0:
         return x
     if _ext.use_hip(x):

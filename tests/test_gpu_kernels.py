@@ -322,6 +322,53 @@ def test_mnist_ops_match_torch():
             _close(a.grad, b.grad, 1e-3, 1e-5, "grad " + name)
 
 
+def test_mnist_fused_head_dropout_and_gradient_sink_match_torch():
+    """The launch-lean forms of the same chain: Linear + log-softmax as one op (its backward folds the log-softmax
+    gradient into the Linear's dx | dw launch), dropout drawn INSIDE the conv / Linear kernels (the stand-alone
+    ``dropout_mask`` kernel reproduces the same counter-hash stream, so the stock-op reference can use its masks), and
+    every weight gradient added straight into a FlatParams buffer (no tensors returned to autograd)."""
+    from distributedpytorch_amd import ops
+    from distributedpytorch_amd.models import mnist
+    from distributedpytorch_amd.parallel.flat import FlatParams
+    C_ = _C()
+    torch.manual_seed(1)
+    B = 40
+    net = mnist.Net(seed=77).to(DEV).train()
+    flat = FlatParams(net, use_lp=False)
+    flat.install_sink(None)
+    flat.grad.fill_(0.25)                                  # gradients are ADDED to what is there
+    x = torch.randn(B, 1, 28, 28, device=DEV, requires_grad=True)
+    t = torch.randint(0, 10, (B,), device=DEV)
+    net._drop.step = 4                                     # host-side counter: the next draws are steps 5 and 6
+    off2d, off1d = 5 * 1_000_003 + 0, 6 * 1_000_003 + 7
+    loss = mnist.nll_loss(net(x), t)
+    loss.backward()
+    torch.cuda.synchronize()
+    m2d = C_.dropout_mask(B * 20, 0.5, 77, off2d, x, None).cpu().view(B, 20, 1, 1)
+    m1d = C_.dropout_mask(B * 50, 0.5, 77, off1d, x, None).cpu().view(B, 50)
+    assert 0.3 < float((m2d > 0).float().mean()) < 0.7 and 0.3 < float((m1d > 0).float().mean()) < 0.7
+    ref = {n: p.detach().cpu().clone().requires_grad_() for n, p in net.named_parameters()}
+    xr = x.detach().cpu().requires_grad_()
+    h = F.relu(F.max_pool2d(F.conv2d(xr, ref["conv1.weight"], ref["conv1.bias"]), 2))
+    h = F.relu(F.max_pool2d(F.conv2d(h, ref["conv2.weight"], ref["conv2.bias"]) * m2d, 2)).view(-1, 320)
+    h = F.relu(F.linear(h, ref["fc1.weight"], ref["fc1.bias"])) * m1d
+    lossr = F.nll_loss(F.log_softmax(F.linear(h, ref["fc2.weight"], ref["fc2.bias"]), dim=1), t.cpu())
+    lossr.backward()
+    _close(loss, lossr, 1e-4, 1e-5, "loss with in-kernel dropout")
+    _close(x.grad, xr.grad, 1e-3, 1e-6, "grad x")
+    for n, p in net.named_parameters():
+        a, b = flat.slice_of(p)
+        _close(flat.grad[a:b].view(p.shape) - 0.25, ref[n].grad, 1e-3, 2e-5, "sunk grad " + n)
+    # eval mode: no dropout, same op
+    net.eval()
+    with torch.no_grad():
+        lp = net(x)
+    hr = F.relu(F.max_pool2d(F.conv2d(xr, ref["conv1.weight"], ref["conv1.bias"]), 2))
+    hr = F.relu(F.max_pool2d(F.conv2d(hr, ref["conv2.weight"], ref["conv2.bias"]), 2)).view(-1, 320)
+    hr = F.relu(F.linear(hr, ref["fc1.weight"], ref["fc1.bias"]))
+    _close(lp, F.log_softmax(F.linear(hr, ref["fc2.weight"], ref["fc2.bias"]), dim=1).detach(), 1e-4, 1e-4, "eval log-probs")
+
+
 def test_lm_head_shaped_linear_matches_fp32_reference_on_both_gemm_kernels():
     """ops.linear on an LM-head-shaped problem (wide vocabulary, nothing fused): forward, input gradient and weight
     gradient against the fp32 expression, once through csrc/gemm_wide.hip (forced) and once through the 128 x 128
