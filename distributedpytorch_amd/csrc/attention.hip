@@ -1,5 +1,10 @@
 // Causal multi-head self-attention (flash-style, no S x S matrix in memory) for gfx950,
-// head dim 64, qkv packed as [B, T, 3, H, 64] bf16 (the layout the fused QKV GEMM emits).
+// head dim DH = 64 or 128, any sequence length, qkv packed as [B, T, 3, H, DH] bf16 (the layout the fused QKV GEMM emits).
+//
+// Ragged T (T % 128 != 0): the grid covers ceil(T / 128) blocks; rows past T are CLAMPED to row T - 1 when loaded (valid
+// memory, finite data) and never stored.  Keys past T need no extra mask - they are in every real query's future, so
+// the causal mask of the diagonal tiles already removes them; queries past T are given lse = +big in the key-stationary
+// kernel, which makes their probabilities exactly 0.
 //
 // MFMA: v_mfma_f32_32x32x16_bf16 throughout.  The score tile is computed TRANSPOSED
 // (S^T = K . Q^T: keys in the accumulator registers, the query on the lane), so
@@ -15,63 +20,67 @@
 //
 // Workgroup = 4 waves; each wave owns 32 queries (fwd, dQ) or 32 keys (dK/dV); K/V (or
 // Q/dO) tiles of 64 rows are staged through LDS and shared by the 4 waves.
+#include <math.h>
 #include "common.h"
 #include "kernels.h"
 
 namespace dpa {
 namespace {
 
-constexpr int D = 64;
 constexpr int TILE = 64;                 // rows per staged tile
-constexpr int TILE_BYTES = TILE * D * 2; // 8 KiB
 constexpr float NEG_BIG = -1.0e30f;
+template <int DH> constexpr int tile_bytes() { return TILE * DH * 2; }   // 8 / 16 KiB
 
 typedef __attribute__((address_space(3))) short4v* lds_s4_ptr;
 
-// byte offset of element (row, col) in a [64][64] bf16 LDS image; 64-byte granules are
-// XOR-swizzled with bit 1 of the row so the 4 rows of a transposed read hit 4 distinct
-// 64-byte windows of the 256-byte bank row
+// byte offset of element (row, col) in a [64][DH] bf16 LDS image that serves row reads (ds_read_b128) and transposed
+// reads (ds_read_b64_tr_b16) alike.  DH = 64 (128-byte rows): 64-byte granules XOR-swizzled with bit 1 of the row, so
+// the 4 rows of a transposed read hit 4 distinct 64-byte windows of the 256-byte bank row.  DH = 128 (256-byte rows):
+// the 16-byte chunk index XORed with ((row & 3) << 2 | (row >> 2) & 3) - conflict-free for both kinds of read.
+template <int DH>
 __device__ __forceinline__ int img_off(int row, int col) {
-    return row * 128 + ((((col >> 5) ^ (row >> 1)) & 1) << 6) + (col & 31) * 2;
+    if (DH == 64) return row * 128 + ((((col >> 5) ^ (row >> 1)) & 1) << 6) + (col & 31) * 2;
+    return row * 256 + ((((col >> 3) ^ (((row & 3) << 2) | ((row >> 2) & 3))) & 15) << 4) + (col & 7) * 2;
 }
 
-// cooperative load of a 64 x 64 bf16 tile (row stride `rs` elements) into an LDS image
-__device__ __forceinline__ void load_tile(const unsigned short* __restrict__ g, long rs, unsigned char* lds, int tid) {
-    const int c = tid & 7;
+// Global loads of a 64 x DH bf16 tile (row stride `rs` elements, first row `r0`, rows clamped to `rlast`) split in
+// two, so the next tile's loads are in flight under the current tile's MFMAs: fetch_tile issues them into registers,
+// stash_tile writes the registers to the LDS image
+template <int DH>
+__device__ __forceinline__ void fetch_tile(const unsigned short* __restrict__ g, long rs, int r0, int rlast, int tid,
+                                           u32x4 (&r)[DH / 32]) {
+    constexpr int CPR = DH / 8, RSTEP = 256 / CPR;
+    const int c = tid % CPR;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (tid >> 3) + i * 32;
-        const u32x4 v = *(const u32x4*)(g + (long)row * rs + c * 8);
-        *(u32x4*)(lds + img_off(row, c * 8)) = v;
+    for (int i = 0; i < DH / 32; ++i) {
+        int row = r0 + tid / CPR + i * RSTEP;
+        row = row < rlast ? row : rlast;
+        r[i] = *(const u32x4*)(g + (long)row * rs + c * 8);
     }
 }
-
-// the same load split in two, so the next tile's global loads are in flight under the current tile's
-// MFMAs: fetch_tile issues them into registers, stash_tile writes the registers to the LDS image
-__device__ __forceinline__ void fetch_tile(const unsigned short* __restrict__ g, long rs, int tid, u32x4 (&r)[2]) {
-    const int c = tid & 7;
+template <int DH>
+__device__ __forceinline__ void stash_tile(unsigned char* lds, int tid, const u32x4 (&r)[DH / 32]) {
+    constexpr int CPR = DH / 8, RSTEP = 256 / CPR;
+    const int c = tid % CPR;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) r[i] = *(const u32x4*)(g + (long)((tid >> 3) + i * 32) * rs + c * 8);
-}
-__device__ __forceinline__ void stash_tile(unsigned char* lds, int tid, const u32x4 (&r)[2]) {
-    const int c = tid & 7;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) *(u32x4*)(lds + img_off((tid >> 3) + i * 32, c * 8)) = r[i];
+    for (int i = 0; i < DH / 32; ++i) *(u32x4*)(lds + img_off<DH>(tid / CPR + i * RSTEP, c * 8)) = r[i];
 }
 
 // MFMA A/B row fragment: 8 consecutive d of one row (k = 8h + j + 16kk)
+template <int DH>
 __device__ __forceinline__ bf16x8 row_frag(const unsigned char* lds, int row, int kk, int h) {
-    return *(const bf16x8*)(lds + img_off(row, 16 * kk + 8 * h));
+    return *(const bf16x8*)(lds + img_off<DH>(row, 16 * kk + 8 * h));
 }
 
 // transposed A fragment for  Y^T[d][..] += T^T[d x rows] . X[rows x ..]  where X is an
 // accumulator tile used as B operand: element j <-> row rowbase + 8(j>>2) + (j&3)
 // (rowbase already contains 16s + 4h), d = dbase + (lane & 31)
+template <int DH>
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lds, int rowbase, int dbase, int lane) {
     const int gi = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
     const int col = dbase + (gi & 1) * 16 + 4 * tp;
-    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(lds + img_off(rowbase + tq, col)));
-    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(lds + img_off(rowbase + 8 + tq, col)));
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(lds + img_off<DH>(rowbase + tq, col)));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(lds + img_off<DH>(rowbase + 8 + tq, col)));
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
@@ -93,10 +102,11 @@ __device__ __forceinline__ void zero16(floatx16& a) {
     for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 
-// store a transposed accumulator pair (rows = d, col = this lane's token) as bf16 [token][64]
-__device__ __forceinline__ void store_T(unsigned short* __restrict__ dst, const floatx16 (&acc)[2], float scale, int h) {
+// store transposed accumulators (rows = d, col = this lane's token) as bf16 [token][DH]
+template <int DH>
+__device__ __forceinline__ void store_T(unsigned short* __restrict__ dst, const floatx16 (&acc)[DH / 32], float scale, int h) {
 #pragma unroll
-    for (int di = 0; di < 2; ++di)
+    for (int di = 0; di < DH / 32; ++di)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int d = 32 * di + 8 * g + 4 * h;
@@ -108,39 +118,44 @@ __device__ __forceinline__ void store_T(unsigned short* __restrict__ dst, const 
 }
 
 // ------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
+template <int DH>
+__global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_fwd_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
                                                        float* __restrict__ lse, int T, int H, float c_log2) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+    constexpr int KK = DH / 16, DI = DH / 32, TB = tile_bytes<DH>();
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TB];
     unsigned char* Ks = smem;
-    unsigned char* Vs = smem + TILE_BYTES;
+    unsigned char* Vs = smem + TB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane & 31, h = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
     const int q0 = (gridDim.x - 1 - blockIdx.x) * 128, qw0 = q0 + 32 * wave, q = qw0 + ql;
-    const long rs = 3L * H * D;                                     // token stride of qkv
-    const unsigned short* base = qkv + (long)b * T * rs + head * D;   // (b, t=0, q, head)
-    const unsigned short* kbase = base + (long)H * D;
-    const unsigned short* vbase = base + 2L * H * D;
+    const int qc = q < T ? q : T - 1;                               // rows past T: clamped loads, no stores
+    const long rs = 3L * H * DH;                                    // token stride of qkv
+    const unsigned short* base = qkv + (long)b * T * rs + head * DH;  // (b, t=0, q, head)
+    const unsigned short* kbase = base + (long)H * DH;
+    const unsigned short* vbase = base + 2L * H * DH;
 
-    bf16x8 qf[4];
+    bf16x8 qf[KK];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(base + (long)q * rs + 16 * kk + 8 * h);
+    for (int kk = 0; kk < KK; ++kk) qf[kk] = *(const bf16x8*)(base + (long)qc * rs + 16 * kk + 8 * h);
 
-    floatx16 O[2];
-    zero16(O[0]); zero16(O[1]);
+    floatx16 O[DI];
+#pragma unroll
+    for (int di = 0; di < DI; ++di) zero16(O[di]);
     float m = NEG_BIG, l = 0.f;
-    const int ntiles = (q0 + 128) / TILE;
-    u32x4 pk[2], pv[2];
-    fetch_tile(kbase, rs, tid, pk);
-    fetch_tile(vbase, rs, tid, pv);
+    int ntiles = (q0 + 128) / TILE;
+    if (ntiles > (T + TILE - 1) / TILE) ntiles = (T + TILE - 1) / TILE;
+    u32x4 pk[DH / 32], pv[DH / 32];
+    fetch_tile<DH>(kbase, rs, 0, T - 1, tid, pk);
+    fetch_tile<DH>(vbase, rs, 0, T - 1, tid, pv);
     for (int j = 0; j < ntiles; ++j) {
         __syncthreads();
-        stash_tile(Ks, tid, pk);
-        stash_tile(Vs, tid, pv);
+        stash_tile<DH>(Ks, tid, pk);
+        stash_tile<DH>(Vs, tid, pv);
         __syncthreads();
         if (j + 1 < ntiles) {
-            fetch_tile(kbase + (long)(j + 1) * TILE * rs, rs, tid, pk);
-            fetch_tile(vbase + (long)(j + 1) * TILE * rs, rs, tid, pv);
+            fetch_tile<DH>(kbase, rs, (j + 1) * TILE, T - 1, tid, pk);
+            fetch_tile<DH>(vbase, rs, (j + 1) * TILE, T - 1, tid, pv);
         }
         if (j * TILE > qw0 + 31) continue;                       // wave-uniform: every key is in the future
         floatx16 S[2];
@@ -148,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
         for (int t2 = 0; t2 < 2; ++t2) {
             zero16(S[t2]);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                S[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, 32 * t2 + ql, kk, h), qf[kk], S[t2], 0, 0, 0);
+            for (int kk = 0; kk < KK; ++kk)
+                S[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(Ks, 32 * t2 + ql, kk, h), qf[kk], S[t2], 0, 0, 0);
         }
         const bool diag = (j * TILE + TILE - 1) > qw0;             // tile may contain keys > some query of the wave
         float mx = NEG_BIG;
@@ -159,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float s = S[t2][r] * c_log2;
-                    if ((j * TILE + 32 * t2 + acc_row(r, h)) > q) s = NEG_BIG;
+                    if ((j * TILE + 32 * t2 + acc_row(r, h)) > qc) s = NEG_BIG;
                     S[t2][r] = s;
                     mx = fmaxf(mx, s);
                 }
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
         l = l * alpha + rsum;
         m = mn;
 #pragma unroll
-        for (int di = 0; di < 2; ++di)
+        for (int di = 0; di < DI; ++di)
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[di][r] *= alpha;
 #pragma unroll
@@ -198,30 +213,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 pb = pack_regs(S[t2], s);
 #pragma unroll
-                for (int di = 0; di < 2; ++di)
-                    O[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vs, 32 * t2 + 16 * s + 4 * h, 32 * di, lane), pb,
+                for (int di = 0; di < DI; ++di)
+                    O[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<DH>(Vs, 32 * t2 + 16 * s + 4 * h, 32 * di, lane), pb,
                                                                     O[di], 0, 0, 0);
             }
     }
-    const float inv = 1.f / l;
-    store_T(out + ((long)(b * T + q) * H + head) * D, O, inv, h);
-    if (h == 0) lse[((long)b * H + head) * T + q] = (m + log2f(l)) * 0.6931471805599453f;
+    if (q < T) {
+        const float inv = 1.f / l;
+        store_T<DH>(out + ((long)(b * T + q) * H + head) * DH, O, inv, h);
+        if (h == 0) lse[((long)b * H + head) * T + q] = (m + log2f(l)) * 0.6931471805599453f;
+    }
 }
 
 // ------------------------------------------------------------------------------ delta = rowsum(dO * O)
+template <int DH>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const unsigned short* __restrict__ o, const unsigned short* __restrict__ d_o,
                                                          float* __restrict__ delta, int T, int H, long rows) {
-    // one 8-lane group per (b, t, head) row of 64 elements
-    const long row = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
-    const int c = threadIdx.x & 7;
+    // one (DH / 8)-lane group per (b, t, head) row of DH elements
+    constexpr int LPR = DH / 8;
+    const long row = (long)blockIdx.x * (256 / LPR) + (threadIdx.x / LPR);
+    const int c = threadIdx.x % LPR;
     float s = 0.f;
     if (row < rows) {
-        uint4 a = *(const uint4*)(o + row * D + c * 8), g = *(const uint4*)(d_o + row * D + c * 8);
+        uint4 a = *(const uint4*)(o + row * DH + c * 8), g = *(const uint4*)(d_o + row * DH + c * 8);
         float fa[8], fg[8]; unpack8(a, fa); unpack8(g, fg);
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += fa[j] * fg[j];
     }
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+#pragma unroll
+    for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
     if (row < rows && c == 0) {
         const long bt = row / H; const int head = (int)(row - bt * H);
         const long bi = bt / T; const int t = (int)(bt - bi * T);
@@ -230,46 +250,55 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const unsigned short* _
 }
 
 // ------------------------------------------------------------------------------ dK / dV (key-stationary)
-__global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ d_o,
+template <int DH>
+__global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_kv_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ d_o,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           unsigned short* __restrict__ dqkv, int T, int H, float scale) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES + 2 * TILE * 4];
+    constexpr int KK = DH / 16, DI = DH / 32, TB = tile_bytes<DH>();
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TB + 2 * TILE * 4];
     unsigned char* Qs = smem;
-    unsigned char* Os = smem + TILE_BYTES;
-    float* lse_s = (float*)(smem + 2 * TILE_BYTES);
+    unsigned char* Os = smem + TB;
+    float* lse_s = (float*)(smem + 2 * TB);
     float* del_s = lse_s + TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kl = lane & 31, h = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
     const int k0 = blockIdx.x * 128, kw0 = k0 + 32 * wave, key = kw0 + kl;
-    const long rs = 3L * H * D, ors = (long)H * D;
-    const unsigned short* base = qkv + (long)b * T * rs + head * D;
-    const unsigned short* dobase = d_o + (long)b * T * ors + head * D;
+    const int keyc = key < T ? key : T - 1;
+    const long rs = 3L * H * DH, ors = (long)H * DH;
+    const unsigned short* base = qkv + (long)b * T * rs + head * DH;
+    const unsigned short* dobase = d_o + (long)b * T * ors + head * DH;
     const float* lse_b = lse + ((long)b * H + head) * T;
     const float* del_b = delta + ((long)b * H + head) * T;
     const float c_log2 = scale * 1.4426950408889634f;
 
-    bf16x8 kf[4], vf[4];
+    bf16x8 kf[KK], vf[KK];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        kf[kk] = *(const bf16x8*)(base + (long)key * rs + (long)H * D + 16 * kk + 8 * h);
-        vf[kk] = *(const bf16x8*)(base + (long)key * rs + 2L * H * D + 16 * kk + 8 * h);
+    for (int kk = 0; kk < KK; ++kk) {
+        kf[kk] = *(const bf16x8*)(base + (long)keyc * rs + (long)H * DH + 16 * kk + 8 * h);
+        vf[kk] = *(const bf16x8*)(base + (long)keyc * rs + 2L * H * DH + 16 * kk + 8 * h);
     }
-    floatx16 dKt[2], dVt[2];
-    zero16(dKt[0]); zero16(dKt[1]); zero16(dVt[0]); zero16(dVt[1]);
+    floatx16 dKt[DI], dVt[DI];
+#pragma unroll
+    for (int di = 0; di < DI; ++di) { zero16(dKt[di]); zero16(dVt[di]); }
 
-    u32x4 pq[2], po[2];
-    fetch_tile(base + (long)(k0 / TILE) * TILE * rs, rs, tid, pq);
-    fetch_tile(dobase + (long)(k0 / TILE) * TILE * ors, ors, tid, po);
-    for (int jq = k0 / TILE; jq < T / TILE; ++jq) {
+    const int nq = (T + TILE - 1) / TILE;
+    u32x4 pq[DH / 32], po[DH / 32];
+    fetch_tile<DH>(base, rs, (k0 / TILE) * TILE, T - 1, tid, pq);
+    fetch_tile<DH>(dobase, ors, (k0 / TILE) * TILE, T - 1, tid, po);
+    for (int jq = k0 / TILE; jq < nq; ++jq) {
         __syncthreads();
-        stash_tile(Qs, tid, pq);
-        stash_tile(Os, tid, po);
-        if (tid < TILE) { lse_s[tid] = lse_b[jq * TILE + tid] * 1.4426950408889634f; del_s[tid] = del_b[jq * TILE + tid]; }
+        stash_tile<DH>(Qs, tid, pq);
+        stash_tile<DH>(Os, tid, po);
+        if (tid < TILE) {
+            const int qi = jq * TILE + tid;                       // queries past T: lse = +big makes their probabilities 0
+            lse_s[tid] = qi < T ? lse_b[qi] * 1.4426950408889634f : 1.0e30f;
+            del_s[tid] = qi < T ? del_b[qi] : 0.f;
+        }
         __syncthreads();
-        if (jq + 1 < T / TILE) {
-            fetch_tile(base + (long)(jq + 1) * TILE * rs, rs, tid, pq);
-            fetch_tile(dobase + (long)(jq + 1) * TILE * ors, ors, tid, po);
+        if (jq + 1 < nq) {
+            fetch_tile<DH>(base, rs, (jq + 1) * TILE, T - 1, tid, pq);
+            fetch_tile<DH>(dobase, ors, (jq + 1) * TILE, T - 1, tid, po);
         }
         if (jq * TILE + TILE - 1 < kw0) continue;                 // wave-uniform: all queries are before the wave's keys
 #pragma unroll
@@ -279,9 +308,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const unsigned shor
             floatx16 S, dP;
             zero16(S); zero16(dP);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qs, 32 * t2 + kl, kk, h), kf[kk], S, 0, 0, 0);
-                dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Os, 32 * t2 + kl, kk, h), vf[kk], dP, 0, 0, 0);
+            for (int kk = 0; kk < KK; ++kk) {
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(Qs, 32 * t2 + kl, kk, h), kf[kk], S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(Os, 32 * t2 + kl, kk, h), vf[kk], dP, 0, 0, 0);
             }
             // rows = queries (registers), column = this lane's key
             if (qt0 < kw0 + 31) {                                 // diagonal half tile: causal mask
@@ -306,58 +335,65 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const unsigned shor
                 const bf16x8 pb = pack_regs(S, s), dsb = pack_regs(dP, s);
                 const int rowbase = 32 * t2 + 16 * s + 4 * h;
 #pragma unroll
-                for (int di = 0; di < 2; ++di) {
-                    dVt[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Os, rowbase, 32 * di, lane), pb, dVt[di], 0, 0, 0);
-                    dKt[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qs, rowbase, 32 * di, lane), dsb, dKt[di], 0, 0, 0);
+                for (int di = 0; di < DI; ++di) {
+                    dVt[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<DH>(Os, rowbase, 32 * di, lane), pb, dVt[di], 0, 0, 0);
+                    dKt[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<DH>(Qs, rowbase, 32 * di, lane), dsb, dKt[di], 0, 0, 0);
                 }
             }
         }
     }
-    unsigned short* dst = dqkv + (long)(b * T + key) * rs + head * D;
-    store_T(dst + (long)H * D, dKt, 1.f, h);
-    store_T(dst + 2L * H * D, dVt, 1.f, h);
+    if (key < T) {
+        unsigned short* dst = dqkv + (long)(b * T + key) * rs + head * DH;
+        store_T<DH>(dst + (long)H * DH, dKt, 1.f, h);
+        store_T<DH>(dst + 2L * H * DH, dVt, 1.f, h);
+    }
 }
 
 // ------------------------------------------------------------------------------ dQ (query-stationary)
-__global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ d_o,
+template <int DH>
+__global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_q_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ d_o,
                                                          const float* __restrict__ lse, const float* __restrict__ delta,
                                                          unsigned short* __restrict__ dqkv, int T, int H, float scale) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+    constexpr int KK = DH / 16, DI = DH / 32, TB = tile_bytes<DH>();
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TB];
     unsigned char* Ks = smem;
-    unsigned char* Vs = smem + TILE_BYTES;
+    unsigned char* Vs = smem + TB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane & 31, h = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
     const int q0 = (gridDim.x - 1 - blockIdx.x) * 128, qw0 = q0 + 32 * wave, q = qw0 + ql;
-    const long rs = 3L * H * D, ors = (long)H * D;
-    const unsigned short* base = qkv + (long)b * T * rs + head * D;
-    const unsigned short* kbase = base + (long)H * D;
-    const unsigned short* vbase = base + 2L * H * D;
+    const int qc = q < T ? q : T - 1;
+    const long rs = 3L * H * DH, ors = (long)H * DH;
+    const unsigned short* base = qkv + (long)b * T * rs + head * DH;
+    const unsigned short* kbase = base + (long)H * DH;
+    const unsigned short* vbase = base + 2L * H * DH;
     const float c_log2 = scale * 1.4426950408889634f;
 
-    bf16x8 qf[4], dof[4];
+    bf16x8 qf[KK], dof[KK];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        qf[kk] = *(const bf16x8*)(base + (long)q * rs + 16 * kk + 8 * h);
-        dof[kk] = *(const bf16x8*)(d_o + ((long)(b * T + q) * H + head) * D + 16 * kk + 8 * h);
+    for (int kk = 0; kk < KK; ++kk) {
+        qf[kk] = *(const bf16x8*)(base + (long)qc * rs + 16 * kk + 8 * h);
+        dof[kk] = *(const bf16x8*)(d_o + ((long)(b * T + qc) * H + head) * DH + 16 * kk + 8 * h);
     }
-    const float lse_q = lse[((long)b * H + head) * T + q] * 1.4426950408889634f;
-    const float del_q = delta[((long)b * H + head) * T + q];
-    floatx16 dQt[2];
-    zero16(dQt[0]); zero16(dQt[1]);
+    const float lse_q = lse[((long)b * H + head) * T + qc] * 1.4426950408889634f;
+    const float del_q = delta[((long)b * H + head) * T + qc];
+    floatx16 dQt[DI];
+#pragma unroll
+    for (int di = 0; di < DI; ++di) zero16(dQt[di]);
 
-    const int ntiles = (q0 + 128) / TILE;
-    u32x4 pk[2], pv[2];
-    fetch_tile(kbase, rs, tid, pk);
-    fetch_tile(vbase, rs, tid, pv);
+    int ntiles = (q0 + 128) / TILE;
+    if (ntiles > (T + TILE - 1) / TILE) ntiles = (T + TILE - 1) / TILE;
+    u32x4 pk[DH / 32], pv[DH / 32];
+    fetch_tile<DH>(kbase, rs, 0, T - 1, tid, pk);
+    fetch_tile<DH>(vbase, rs, 0, T - 1, tid, pv);
     for (int j = 0; j < ntiles; ++j) {
         __syncthreads();
-        stash_tile(Ks, tid, pk);
-        stash_tile(Vs, tid, pv);
+        stash_tile<DH>(Ks, tid, pk);
+        stash_tile<DH>(Vs, tid, pv);
         __syncthreads();
         if (j + 1 < ntiles) {
-            fetch_tile(kbase + (long)(j + 1) * TILE * rs, rs, tid, pk);
-            fetch_tile(vbase + (long)(j + 1) * TILE * rs, rs, tid, pv);
+            fetch_tile<DH>(kbase, rs, (j + 1) * TILE, T - 1, tid, pk);
+            fetch_tile<DH>(vbase, rs, (j + 1) * TILE, T - 1, tid, pv);
         }
         if (j * TILE > qw0 + 31) continue;
 #pragma unroll
@@ -367,15 +403,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const unsigned short
             floatx16 St, dPt;
             zero16(St); zero16(dPt);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                St = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ks, 32 * t2 + ql, kk, h), qf[kk], St, 0, 0, 0);
-                dPt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vs, 32 * t2 + ql, kk, h), dof[kk], dPt, 0, 0, 0);
+            for (int kk = 0; kk < KK; ++kk) {
+                St = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(Ks, 32 * t2 + ql, kk, h), qf[kk], St, 0, 0, 0);
+                dPt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(Vs, 32 * t2 + ql, kk, h), dof[kk], dPt, 0, 0, 0);
             }
             if (kt0 + 31 > qw0) {                                 // diagonal half tile: causal mask
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kg = kt0 + acc_row(r, h);
-                    const float p = (kg <= q) ? fast_exp2(St[r] * c_log2 - lse_q) : 0.f;
+                    const float p = (kg <= qc) ? fast_exp2(St[r] * c_log2 - lse_q) : 0.f;
                     dPt[r] = p * (dPt[r] - del_q) * scale;
                 }
             } else {
@@ -389,34 +425,47 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const unsigned short
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 dsb = pack_regs(dPt, s);
 #pragma unroll
-                for (int di = 0; di < 2; ++di)
-                    dQt[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ks, 32 * t2 + 16 * s + 4 * h, 32 * di, lane), dsb,
+                for (int di = 0; di < DI; ++di)
+                    dQt[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<DH>(Ks, 32 * t2 + 16 * s + 4 * h, 32 * di, lane), dsb,
                                                                       dQt[di], 0, 0, 0);
             }
         }
     }
-    store_T(dqkv + (long)(b * T + q) * rs + head * D, dQt, 1.f, h);
+    if (q < T) store_T<DH>(dqkv + (long)(b * T + q) * rs + head * DH, dQt, 1.f, h);
+}
+
+template <int DH>
+void launch_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, hipStream_t st) {
+    const float c_log2 = (1.0f / sqrtf((float)DH)) * 1.4426950408889634f;   // 1/sqrt(DH) * log2(e)
+    hipLaunchKernelGGL(attn_fwd_kernel<DH>, dim3((T + 127) / 128, H, B), dim3(256), 0, st, (const unsigned short*)qkv,
+                       (unsigned short*)out, lse, T, H, c_log2);
+}
+
+template <int DH>
+void launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,
+                int B, int T, int H, hipStream_t st) {
+    const long rows = (long)B * T * H;
+    constexpr int RPB = 256 / (DH / 8);
+    const float scale = 1.0f / sqrtf((float)DH);
+    hipLaunchKernelGGL(attn_delta_kernel<DH>, dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, st, (const unsigned short*)out,
+                       (const unsigned short*)dout, delta, T, H, rows);
+    hipLaunchKernelGGL(attn_bwd_kv_kernel<DH>, dim3((T + 127) / 128, H, B), dim3(256), 0, st, (const unsigned short*)qkv,
+                       (const unsigned short*)dout, lse, delta, (unsigned short*)dqkv, T, H, scale);
+    hipLaunchKernelGGL(attn_bwd_q_kernel<DH>, dim3((T + 127) / 128, H, B), dim3(256), 0, st, (const unsigned short*)qkv,
+                       (const unsigned short*)dout, lse, delta, (unsigned short*)dqkv, T, H, scale);
 }
 
 }  // namespace
 
 void attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int Dh, hipStream_t st) {
-    (void)Dh;
-    const float c_log2 = 0.125f * 1.4426950408889634f;   // 1/sqrt(64) * log2(e)
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(T / 128, H, B), dim3(256), 0, st, (const unsigned short*)qkv, (unsigned short*)out,
-                       lse, T, H, c_log2);
+    if (Dh == 128) launch_fwd<128>(qkv, out, lse, B, T, H, st);
+    else launch_fwd<64>(qkv, out, lse, B, T, H, st);
 }
 
 void attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,
                    int B, int T, int H, int Dh, hipStream_t st) {
-    (void)Dh;
-    const long rows = (long)B * T * H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, (const unsigned short*)out,
-                       (const unsigned short*)dout, delta, T, H, rows);
-    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(T / 128, H, B), dim3(256), 0, st, (const unsigned short*)qkv,
-                       (const unsigned short*)dout, lse, delta, (unsigned short*)dqkv, T, H, 0.125f);
-    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(T / 128, H, B), dim3(256), 0, st, (const unsigned short*)qkv,
-                       (const unsigned short*)dout, lse, delta, (unsigned short*)dqkv, T, H, 0.125f);
+    if (Dh == 128) launch_bwd<128>(qkv, out, dout, lse, dqkv, delta, B, T, H, st);
+    else launch_bwd<64>(qkv, out, dout, lse, dqkv, delta, B, T, H, st);
 }
 
 }  // namespace dpa

@@ -105,9 +105,9 @@ void embedding_bwd(const Tensor& tok, const Tensor& dy, Tensor& dwte, Tensor& dw
 // qkv [B,T,3,H,D] bf16 -> (out [B,T,H,D] bf16, lse [B,H,T] fp32)
 std::vector<Tensor> attention_fwd(const Tensor& qkv) {
     CHECK_BF16(qkv);
-    TORCH_CHECK(qkv.dim() == 5 && qkv.size(2) == 3 && qkv.size(4) == 64, "attention: qkv must be [B,T,3,H,64]");
+    TORCH_CHECK(qkv.dim() == 5 && qkv.size(2) == 3 && (qkv.size(4) == 64 || qkv.size(4) == 128), "attention: qkv must be [B,T,3,H,64|128]");
     const int64_t B = qkv.size(0), T = qkv.size(1), H = qkv.size(3), D = qkv.size(4);
-    TORCH_CHECK(T % 128 == 0, "attention: T must be a multiple of 128");
+    TORCH_CHECK(T >= 1 && B >= 1 && H >= 1 && qkv.numel() < (1ll << 31), "attention: empty or oversized problem");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(qkv.device());
     Tensor out = torch::empty({B, T, H, D}, qkv.options());
     Tensor lse = torch::empty({B, H, T}, qkv.options().dtype(at::kFloat));
@@ -117,9 +117,9 @@ std::vector<Tensor> attention_fwd(const Tensor& qkv) {
 
 Tensor attention_bwd(const Tensor& qkv, const Tensor& out, const Tensor& dout, const Tensor& lse) {
     CHECK_BF16(qkv); CHECK_BF16(out); CHECK_BF16(dout); CHECK_F32(lse);
-    TORCH_CHECK(qkv.dim() == 5 && qkv.size(2) == 3 && qkv.size(4) == 64, "attention_bwd: qkv must be [B,T,3,H,64]");
+    TORCH_CHECK(qkv.dim() == 5 && qkv.size(2) == 3 && (qkv.size(4) == 64 || qkv.size(4) == 128), "attention_bwd: qkv must be [B,T,3,H,64|128]");
     const int64_t B = qkv.size(0), T = qkv.size(1), H = qkv.size(3), D = qkv.size(4);
-    TORCH_CHECK(T % 128 == 0 && out.numel() == B * T * H * D && dout.numel() == out.numel() && lse.numel() == B * H * T, "attention_bwd: shapes");
+    TORCH_CHECK(T >= 1 && out.numel() == B * T * H * D && dout.numel() == out.numel() && lse.numel() == B * H * T, "attention_bwd: shapes");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(qkv.device());
     Tensor dqkv = torch::empty_like(qkv);
     Tensor delta = torch::empty({B, H, T}, lse.options());

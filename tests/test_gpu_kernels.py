@@ -483,11 +483,12 @@ def test_layernorm_gelu_embedding():
     _close(wpe.grad, wper.grad, 1e-3, 1e-3, "dwpe")
 
 
-@pytest.mark.parametrize("B,T,H", [(1, 128, 1), (2, 256, 3), (1, 512, 2)])
-def test_causal_attention_fwd_bwd(B, T, H):
+# ragged lengths (T % 128 != 0: 1, 200 and 1000 - the analogue of the reference's ragged last batches) and both head sizes
+@pytest.mark.parametrize("B,T,H,D", [(1, 128, 1, 64), (2, 256, 3, 64), (1, 512, 2, 64), (2, 200, 2, 64), (1, 1000, 2, 64),
+                                     (1, 1, 1, 64), (1, 65, 2, 64), (2, 256, 2, 128), (1, 200, 3, 128), (1, 1000, 1, 128)])
+def test_causal_attention_fwd_bwd(B, T, H, D):
     """Flash attention kernels vs the fp32 softmax(QK^T/sqrt(d))V oracle (ops/tfm.py CPU path)."""
     from distributedpytorch_amd import ops
-    D = 64
     qkv = _rand_bf16(B, T, 3 * H * D, seed=31).requires_grad_()
     out = ops.causal_attention(qkv, H)
     dout = _rand_bf16(B, T, H * D, seed=32)
