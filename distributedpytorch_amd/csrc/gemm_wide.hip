@@ -521,7 +521,10 @@ bool wide_gemm_eligible(const ConvArgs& a) {
     if (min_tiles == 1) return true;
     if (nk < 12) return false;
     if (s > 1 && nk < 96) return false;
-    return tiles * s >= min_tiles;
+    // enough work for several items per workgroup, counted in tile-K-steps so that the answer does not depend on the
+    // split factor the cost model happens to pick (the LM head's input gradient is 96 tiles x 786 K-steps: at split 5
+    // it is 480 items and fell back to the 128 x 128 kernel at 1000 us instead of 554 us)
+    return tiles * s >= min_tiles || tiles * (long)nk >= 40L * min_tiles;
 }
 
 void gemm_wide(const ConvArgs& a, hipStream_t st) {
