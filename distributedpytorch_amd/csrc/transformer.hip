@@ -51,8 +51,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const unsigned short
     }
 }
 
+// One wave per row, LN_BWD_WAVES waves per workgroup, ONE partial (dgamma, dbeta) row per workgroup.  The row loop is a
+// chain load -> two wave reductions -> store, i.e. one memory round trip per row per wave: with 4 waves on a CU and
+// no prefetch it ran at 42 us for 8192 x 768 (HBM time: 10 us).  Eight waves per workgroup and the NEXT row's loads
+// issued before the current row is reduced keep four times as many rows in flight without adding partial rows to fold.
+constexpr int LN_BWD_WAVES = 8;
 template <int NCH>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
+__global__ __launch_bounds__(LN_BWD_WAVES * 64) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
                                                             const float* __restrict__ g, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, unsigned short* __restrict__ dx,
                                                             float* __restrict__ dg_part, float* __restrict__ db_part,
@@ -64,8 +69,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
     for (int k = 0; k < NCH; ++k)
 #pragma unroll
         for (int j = 0; j < 8; ++j) { dg[k][j] = 0.f; db[k][j] = 0.f; }
-    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
-        const float m = mean[row], rs = rstd[row];
+    const long rstep = (long)gridDim.x * LN_BWD_WAVES;
+    long row = (long)blockIdx.x * LN_BWD_WAVES + wave;
+    uint4 ndy[NCH], nx[NCH], nad[NCH];
+    float nm = 0.f, nrs = 0.f;
+#define DPA_LN_FETCH(R)                                                                         \
+    if ((R) < rows) {                                                                           \
+        nm = mean[R]; nrs = rstd[R];                                                            \
+        _Pragma("unroll") for (int k = 0; k < NCH; ++k) {                                       \
+            const int ch = lane + k * 64;                                                       \
+            if (ch < nch) {                                                                     \
+                ndy[k] = *(const uint4*)(dy + (R) * C + ch * 8);                                \
+                nx[k] = *(const uint4*)(x + (R) * C + ch * 8);                                  \
+                if (addend != nullptr) nad[k] = *(const uint4*)(addend + (R) * C + ch * 8);     \
+            }                                                                                   \
+        }                                                                                       \
+    }
+    DPA_LN_FETCH(row)
+    for (; row < rows; row += rstep) {
+        const float m = nm, rs = nrs;
+        uint4 cdy[NCH], cx[NCH], cad[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) { cdy[k] = ndy[k]; cx[k] = nx[k]; cad[k] = nad[k]; }
+        const long nrow = row + rstep;
+        DPA_LN_FETCH(nrow)                              // in flight under this row's arithmetic and reductions
         float xh[NCH][8], gy[NCH][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -73,8 +100,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
             const int ch = lane + k * 64;
             if (ch < nch) {
                 float d[8], xv[8];
-                { uint4 u = *(const uint4*)(dy + row * C + ch * 8); unpack8(u, d); }
-                { uint4 u = *(const uint4*)(x + row * C + ch * 8); unpack8(u, xv); }
+                unpack8(cdy[k], d);
+                unpack8(cx[k], xv);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float h = (xv[j] - m) * rs;
@@ -96,7 +123,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
                 for (int j = 0; j < 8; ++j) o[j] = rs * (gy[k][j] - s1 - xh[k][j] * s2);
                 if (addend != nullptr) {           // gradient arriving over the residual connection around this LayerNorm
                     float ad[8];
-                    { const uint4 u = *(const uint4*)(addend + row * C + ch * 8); unpack8(u, ad); }
+                    unpack8(cad[k], ad);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] += ad[j];
                 }
@@ -104,8 +131,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
             }
         }
     }
-    // fold the 4 waves of the block through LDS, then one partial row per block
-    __shared__ float red[4][64 * 8 + 8];
+#undef DPA_LN_FETCH
+    // fold the waves of the block through LDS, then one partial row per block
+    __shared__ float red[LN_BWD_WAVES][64 * 8 + 8];
     for (int pass = 0; pass < 2 * NCH; ++pass) {
         const int k = pass >> 1;
         const bool is_g = (pass & 1) == 0;
@@ -117,8 +145,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
         if (wave == 0 && ch < nch) {
             float* outp = (is_g ? dg_part : db_part) + (long)blockIdx.x * C + ch * 8;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                outp[j] = red[0][lane * 8 + j] + red[1][lane * 8 + j] + red[2][lane * 8 + j] + red[3][lane * 8 + j];
+            for (int j = 0; j < 8; ++j) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < LN_BWD_WAVES; ++w) t += red[w][lane * 8 + j];
+                outp[j] = t;
+            }
         }
     }
 }
@@ -231,7 +263,7 @@ inline int grid_for(long n) { long b = (n + 255) / 256; if (b > 4096) b = 4096; 
 }  // namespace
 
 int layernorm_partial_rows(long rows) {
-    long b = (rows + 3) / 4;
+    long b = (rows + LN_BWD_WAVES - 1) / LN_BWD_WAVES;
     // one workgroup per CU.  Measured in the GPT-2 step (8192 x 768, fold on the side stream), tok/s: 128 blocks 580k,
     // 256: 624.6k, 384: 617k, 512: 620k, 1024: 616k, 2048: 599k - every extra block is another partial row to fold
     static const long cap = [] { const char* e = getenv("DPA_LN_ROWS"); return e ? atol(e) : 256L; }();
@@ -252,7 +284,7 @@ void layernorm_fwd(const void* x, const float* g, const float* b, void* y, float
 void layernorm_bwd(const void* dy, const void* x, const float* g, const float* mean, const float* rstd,
                    void* dx, float* dg_partial, float* db_partial, int partial_rows, long rows, int C, const void* addend,
                    hipStream_t st) {
-#define DPA_LN_BWD(NCH_) hipLaunchKernelGGL(layernorm_bwd_kernel<NCH_>, dim3(partial_rows), dim3(256), 0, st, \
+#define DPA_LN_BWD(NCH_) hipLaunchKernelGGL(layernorm_bwd_kernel<NCH_>, dim3(partial_rows), dim3(LN_BWD_WAVES * 64), 0, st, \
         (const unsigned short*)dy, (const unsigned short*)x, g, mean, rstd, (unsigned short*)dx, dg_partial, db_partial, rows, C, \
         (const unsigned short*)addend)
     if (C <= 512) DPA_LN_BWD(1); else if (C <= 1024) DPA_LN_BWD(2); else DPA_LN_BWD(4);
