@@ -148,9 +148,10 @@ def pp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, sta
         if dp is not None:
             opt.grad_scale = dp.grad_scale
         eng = PipelineStage(stage_mod, pp_comm, loss_fn, n_micro=n_micro, schedule=schedule, dp=dp)
-        losses = []
+        losses, slots = [], []
         for s in range(steps):
             loss = eng.train_step(batch, x if eng.first else None, y if eng.last else None)
+            slots.append(eng._slots.allocated)
             if s == 0:
                 scale = opt.grad_scale if dp is not None else 1.0
                 if share_gpu:
@@ -160,7 +161,7 @@ def pp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, sta
             opt.step()
             if loss is not None:
                 losses.append(float(loss))
-        torch.save({"losses": losses}, os.path.join(out_dir, f"final_r{replica}_s{stage}.pt"))
+        torch.save({"losses": losses, "slots": slots}, os.path.join(out_dir, f"final_r{replica}_s{stage}.pt"))
         from ..checkpoint import save_checkpoint
         save_checkpoint(os.path.join(out_dir, f"ckpt_r{replica}.pt"), stage_mod, opt, 0, comm=dp_comm, pipeline_comm=pp_comm)
     world.barrier()

@@ -91,6 +91,21 @@ def test_four_stage_resnet_1f1b(tmp_path):
     assert "head.fc.weight" in sd and "block2.downsample.0.weight" in sd
 
 
+def test_receive_slot_pool_stops_allocating_after_the_first_step(tmp_path):
+    """The pipeline's receive slots are a bounded pool: every step after the first re-uses the
+    slots of the one before - at most (micro-batches live on the stage) per direction, never one per micro-batch."""
+    url = f"tcp://127.0.0.1:{T.free_port()}"
+    stages, n_micro, steps = 3, 6, 4
+    launch.spawn(T.pp_worker, [stages], 0, args=(url, "tiny_resnet", str(tmp_path), stages, 1, n_micro, "1f1b", 12, steps))
+    for s in range(stages):
+        slots = torch.load(tmp_path / f"final_r0_s{s}.pt", weights_only=True)["slots"]
+        assert len(slots) == steps and slots[-1] == slots[0], (s, slots)     # nothing allocated after step 1
+        directions = (1 if s > 0 else 0) + (1 if s < stages - 1 else 0)
+        assert slots[0] <= directions * n_micro, (s, slots)
+        if s > 0 and s < stages - 1:
+            assert slots[0] < 2 * n_micro, (s, slots)                        # 1F1B keeps fewer than all of them live
+
+
 def test_dp_x_pp_hybrid_2x2(tmp_path):
     url = f"tcp://127.0.0.1:{T.free_port()}"
     launch.spawn(T.pp_worker, [4], 0, args=(url, "mnist", str(tmp_path), 2, 2, 2, "1f1b", 8, 2))
