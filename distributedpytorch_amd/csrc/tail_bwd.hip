@@ -298,30 +298,300 @@ __global__ __launch_bounds__(256, 1) void tail_bwd_kernel(TailBwdArgs a, int ste
 }
 #undef TB_LOAD_HALF
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same kernel for 128 -> 512 channels (stage 2 of a ResNet).  What changes: the filter is 128 KiB, so with it
+// resident only a 16-pixel tile fits beside it (g 16 KiB + xin 4 + dx 4 + coefficients 6 = 158 KiB, one workgroup per
+// CU); the filter gradient is 512 x 128 fp32 = 256 KiB of accumulators, i.e. 8 waves x 128 registers; the input
+// gradient of a 16-pixel tile is 8 column blocks of v_mfma_f32_16x16x32_bf16, one per wave.  ONE tile (46 KB per CU)
+// is prefetched: 204 us against 251 us for the three kernels, 2.8 TB/s - latency-bound, not bandwidth-bound.  A second
+// register set (two tiles in flight) does not fit beside the accumulators: it spilled 53 VGPRs and ran at 301 us.
+constexpr int T2_R = 16, T2_CM = 128, T2_CO = 512, T2_NT = 512;
+constexpr int D2_ROWB = T2_CO * 2, X2_ROWB = T2_CM * 2;
+constexpr int D2_BYTES = T2_R * D2_ROWB;     // 16 KiB
+constexpr int X2_BYTES = T2_R * X2_ROWB;     //  4 KiB
+constexpr int O2_BYTES = T2_R * X2_ROWB;     //  4 KiB
+constexpr int W2_BYTES = T2_CM * D2_ROWB;    // 128 KiB
+constexpr int K2_BYTES = 3 * T2_CO * 4;      //  6 KiB
+constexpr int T2_LDS = D2_BYTES + X2_BYTES + O2_BYTES + W2_BYTES + K2_BYTES;
+static_assert(T2_LDS <= 160 * 1024, "stage-2 tail kernel must fit one CU's LDS");
+
+__device__ __forceinline__ int d2_off(int row, int ch) {
+    return row * D2_ROWB + ((ch & ~15) << 4) + (((ch & 15) ^ xor_key(row)) << 4);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(T2_NT) void tail_bwd_kernel_128(TailBwdArgs a, int steps_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
+    unsigned char* const dimg = tsm;
+    unsigned char* const ximg = tsm + D2_BYTES;
+    unsigned char* const oimg = ximg + X2_BYTES;
+    unsigned char* const wimg = oimg + O2_BYTES;
+    float* const coef = (float*)(wimg + W2_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long P = a.P;
+    const long p_begin = (long)blockIdx.x * steps_per_wg * T2_R;
+    long p_end = p_begin + (long)steps_per_wg * T2_R;
+    if (p_end > P) p_end = P;
+    if (p_begin >= p_end) return;
+    const int nsteps = (int)((p_end - p_begin + T2_R - 1) / T2_R);
+
+    const unsigned dbytes = (unsigned)p_end * (unsigned)D2_ROWB, xbytes = (unsigned)p_end * (unsigned)X2_ROWB;
+    const __amdgpu_buffer_rsrc_t dors = __builtin_amdgcn_make_buffer_rsrc((void*)a.dout, 0, dbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t crrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.craw, 0, dbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t kors = __builtin_amdgcn_make_buffer_rsrc((void*)a.kout, 0, a.kout ? dbytes >> 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xirs = __builtin_amdgcn_make_buffer_rsrc((void*)a.xin, 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t sxrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.sx, 0, STATS ? xbytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t smrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.smask, 0, STATS ? xbytes >> 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dxrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.dx, 0, xbytes, 0x00020000);
+
+    {
+        const uint4* wsrc = (const uint4*)a.wt;                 // [cm][co]: 128 rows x 64 chunks
+#pragma unroll
+        for (int i = 0; i < T2_CM * (T2_CO / 8) / T2_NT; ++i) {
+            const int q = tid + T2_NT * i, row = q >> 6, ch = q & 63;
+            *(uint4*)(wimg + d2_off(row, ch)) = wsrc[q];
+        }
+        for (int i = tid; i < T2_CO; i += T2_NT) {
+            coef[i] = a.cA[i]; coef[T2_CO + i] = a.cB[i]; coef[2 * T2_CO + i] = a.cC[i];
+        }
+    }
+
+    // ---- staging roles ----
+    const int d_ch = tid & 63, d_row0 = tid >> 6;               // 2 chunks: rows d_row0 + 8 i
+    const bool xrole = tid < 256;                               // wave-uniform: waves 0..3 also stage xin / finish dx
+    const int x_ch = tid & 15, x_row = (tid >> 4) & 15;
+    unsigned d_goff = ((unsigned)(p_begin + d_row0) * (unsigned)T2_CO + (unsigned)d_ch * 8u) * 2u;
+    unsigned x_goff = ((unsigned)(p_begin + x_row) * (unsigned)T2_CM + (unsigned)x_ch * 8u) * 2u;
+    const int d_lds0 = d2_off(d_row0, d_ch), d_lds1 = d2_off(d_row0 + 8, d_ch);
+    const int x_lds = x_row * X2_ROWB + (((((x_ch >> 2) ^ (x_row & 3)) << 2) | (x_ch & 3)) << 4);
+    const int o_lds = x_row * X2_ROWB + ((x_ch ^ (x_row & 7)) << 4);
+
+    u32x4 dreg[2], creg[2], xreg, sreg;
+    unsigned mreg[2], smr = 0;
+#define T2_LOAD()                                                                                           \
+    {                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                     \
+            const unsigned o = d_goff + (unsigned)(i * 8 * D2_ROWB);                                        \
+            dreg[i] = __builtin_amdgcn_raw_buffer_load_b128(dors, o, 0, 0);                                 \
+            creg[i] = __builtin_amdgcn_raw_buffer_load_b128(crrs, o, 0, 0);                                 \
+            mreg[i] = a.kout ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(kors, o >> 4, 0, 0) : 0xffu;   \
+        }                                                                                                   \
+        if (xrole) {                                                                                        \
+            xreg = __builtin_amdgcn_raw_buffer_load_b128(xirs, x_goff, 0, 0);                               \
+            if (STATS) {                                                                                    \
+                sreg = __builtin_amdgcn_raw_buffer_load_b128(sxrs, x_goff, 0, 0);                           \
+                smr = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(smrs, x_goff >> 4, 0, 0);               \
+            }                                                                                               \
+        }                                                                                                   \
+        d_goff += (unsigned)(T2_R * D2_ROWB); x_goff += (unsigned)(T2_R * X2_ROWB);                         \
+    }
+
+    // ---- wgrad roles: wave = 64 out channels x all 128 in channels; one 16-pixel slice per tile ----
+    floatx16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int gi = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+    const int kofs = 8 * (gi >> 1) + tq;
+    const int cofs = (gi & 1) * 16 + 4 * tp;
+    int a_tr[2][2], b_tr[4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = kofs + 4 * h;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int col = wave * 64 + i * 32 + cofs;
+            a_tr[i][h] = d2_off(row, col >> 3) + 8 * ((col >> 2) & 1);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xc = j * 32 + cofs;
+            b_tr[j][h] = row * X2_ROWB + (((xc >> 5) ^ (row & 3)) << 6) + (xc & 31) * 2;
+        }
+    }
+
+    // ---- dgrad roles: wave = 16 in channels x the tile's 16 pixels, all 512 out channels (16x16x32 MFMAs) ----
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int w_row = wave * 16 + l15;
+    const int w_base = w_row * D2_ROWB, w_x = (q4 ^ xor_key(w_row)) << 4;
+    const int g_base = l15 * D2_ROWB, g_x = (q4 ^ xor_key(l15)) << 4;
+    const int o_st = l15 * X2_ROWB + (((2 * wave + (q4 >> 1)) ^ (l15 & 7)) << 4) + 8 * (q4 & 1);
+
+    float ssum[8], qsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; qsum[j] = 0.f; }
+
+    T2_LOAD()
+    __syncthreads();                                    // filter + coefficients visible
+    for (int t = 0; t < nsteps; ++t) {
+        const long row_base = p_begin + (long)t * T2_R;
+        u32x4 sxe; unsigned sme = 0;
+        {
+            float kA[8], kB[8], kC[8];
+            {
+                const float4* c4 = (const float4*)(coef + d_ch * 8);
+                const float4 a0 = c4[0], a1 = c4[1], b0 = c4[T2_CO / 4], b1 = c4[T2_CO / 4 + 1], c0 = c4[T2_CO / 2], c1 = c4[T2_CO / 2 + 1];
+                kA[0] = a0.x; kA[1] = a0.y; kA[2] = a0.z; kA[3] = a0.w; kA[4] = a1.x; kA[5] = a1.y; kA[6] = a1.z; kA[7] = a1.w;
+                kB[0] = b0.x; kB[1] = b0.y; kB[2] = b0.z; kB[3] = b0.w; kB[4] = b1.x; kB[5] = b1.y; kB[6] = b1.z; kB[7] = b1.w;
+                kC[0] = c0.x; kC[1] = c0.y; kC[2] = c0.z; kC[3] = c0.w; kC[4] = c1.x; kC[5] = c1.y; kC[6] = c1.z; kC[7] = c1.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float dv[8], cv[8], o[8];
+                unpack8(uint4{dreg[i].x, dreg[i].y, dreg[i].z, dreg[i].w}, dv);
+                unpack8(uint4{creg[i].x, creg[i].y, creg[i].z, creg[i].w}, cv);
+                const unsigned m = mreg[i];
+                const bool live = row_base + d_row0 + 8 * i < p_end;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gd = ((m >> j) & 1u) ? dv[j] : 0.f;
+                    const float v = __builtin_fmaf(kA[j], gd, __builtin_fmaf(kB[j], cv[j], kC[j]));   // as bn_bwd_apply_kernel
+                    o[j] = live ? v : 0.f;
+                }
+                const uint4 pk = pack8(o);
+                *(u32x4*)(dimg + (i == 0 ? d_lds0 : d_lds1)) = u32x4{pk.x, pk.y, pk.z, pk.w};
+            }
+            if (xrole) {
+                *(u32x4*)(ximg + x_lds) = xreg;
+                if (STATS) { sxe = sreg; sme = smr; }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        T2_LOAD()                                       // tile t + 1 flies during the MFMA phase (past p_end: zeros)
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+
+        // ---- wgrad: dw[co][cm] += g^T xin over the tile's 16 pixels ----
+        {
+            bf16x8 af[2], bf[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                short4v lo = tr_read(dimg + a_tr[i][0]);
+                short4v hi = tr_read(dimg + a_tr[i][1]);
+                af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                short4v xl = tr_read(ximg + b_tr[j][0]);
+                short4v xh = tr_read(ximg + b_tr[j][1]);
+                bf[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(xl, xh, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        // ---- dgrad, transposed: dxT[cm][p] = sum_co wt[cm][co] * g[p][co] ----
+        floatx4 dacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < T2_CO / 32; ++ks) {
+            const int c0 = ((4 * ks) & 15) << 4, half = (ks >> 2) << 8;
+            const bf16x8 wf = *(const bf16x8*)(wimg + w_base + half + (c0 ^ w_x));
+            const bf16x8 gf = *(const bf16x8*)(dimg + g_base + half + (c0 ^ g_x));
+            dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, gf, dacc, 0, 0, 0);
+        }
+        {
+            uint2 v;
+            v.x = pack_bf16x2(dacc[0], dacc[1]);
+            v.y = pack_bf16x2(dacc[2], dacc[3]);
+            *(uint2*)(oimg + o_st) = v;
+        }
+        __syncthreads();                                // dx tile complete; g / xin tiles free for the next transform
+        if (xrole) {
+            const u32x4 v = *(const u32x4*)(oimg + o_lds);
+            const long row = row_base + x_row;
+            const unsigned off = row < p_end ? (unsigned)((row * T2_CM + x_ch * 8) * 2) : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_buffer_store_b128(v, dxrs, off, 0, 0);
+            if (STATS) {
+                float g[8], xf[8];
+                unpack8(uint4{v.x, v.y, v.z, v.w}, g);
+                unpack8(uint4{sxe.x, sxe.y, sxe.z, sxe.w}, xf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gm = ((sme >> j) & 1u) ? g[j] : 0.f;     // rows past p_end: mask and sx read as zero
+                    ssum[j] += gm; qsum[j] += gm * xf[j];
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    {
+        const int ccol = lane & 31, rhalf = (lane >> 5) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+                    atomicAdd(a.dw + (long)row * T2_CM + j * 32 + ccol, acc[i][j][r]);
+                }
+    }
+    if (STATS) {
+        __syncthreads();
+        float* red = (float*)dimg;                      // [256 threads][17] = 17 KiB over the g + xin tiles
+        if (xrole) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { red[tid * 17 + j] = ssum[j]; red[tid * 17 + 8 + j] = qsum[j]; }
+        }
+        __syncthreads();
+        if (tid < 2 * T2_CM) {
+            const int which = tid / T2_CM, c = tid % T2_CM, ch = c >> 3, j = c & 7;
+            float s = 0.f;
+            for (int r = 0; r < 16; ++r) s += red[(r * 16 + ch) * 17 + which * 8 + j];
+            atomicAdd(a.stats + ((long)(blockIdx.x % a.stats_rows) * 2 + which) * T2_CM + c, s);
+        }
+    }
+}
+#undef T2_LOAD
+
 }  // namespace
 
 bool tail_bwd_supported(const TailBwdArgs& a) {
     static const bool off = [] { const char* e = getenv("DPA_NO_TAIL_BWD"); return e && atoi(e) != 0; }();
-    return !off && !deterministic() && a.CM == TB_CM && a.CO == TB_CO && a.P > 0 && a.P * (long)TB_CO * 2 < (1ll << 31) - (1ll << 20);
+    static const bool off128 = [] { const char* e = getenv("DPA_NO_TAIL_BWD_128"); return e && atoi(e) != 0; }();
+    const bool shape = (a.CM == TB_CM && a.CO == TB_CO) || (!off128 && a.CM == T2_CM && a.CO == T2_CO);
+    return !off && !deterministic() && shape && a.P > 0 && a.P * (long)a.CO * 2 < (1ll << 31) - (1ll << 20);
+}
+
+template <class K>
+static void allow_lds(K kernel, int bytes) {
+    const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        fprintf(stderr, "tail_bwd: cannot allow %d bytes of LDS: %s\n", bytes, hipGetErrorString(e));
+        abort();
+    }
 }
 
 void tail_bwd(const TailBwdArgs& a, hipStream_t st) {
     static bool prepared = false;
     if (!prepared) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)tail_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS);
-        hipError_t e2 = hipFuncSetAttribute((const void*)tail_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS);
-        if (e1 != hipSuccess || e2 != hipSuccess) {
-            fprintf(stderr, "tail_bwd: cannot allow %d bytes of LDS: %s\n", TB_LDS, hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-            abort();
-        }
+        allow_lds(tail_bwd_kernel<true>, TB_LDS); allow_lds(tail_bwd_kernel<false>, TB_LDS);
+        allow_lds(tail_bwd_kernel_128<true>, T2_LDS); allow_lds(tail_bwd_kernel_128<false>, T2_LDS);
         prepared = true;
     }
-    // one workgroup per CU (83 KiB of LDS each): 254 us at 256 workgroups, 264 us at 512 on the stage-1 shape
+    // one workgroup per CU (83 / 158 KiB of LDS each): 254 us at 256 workgroups, 264 us at 512 on the stage-1 shape
     static const int target = [] { const char* e = getenv("DPA_TAIL_BWD_BLOCKS"); return e ? atoi(e) : 256; }();
-    const long steps = (a.P + TB_R - 1) / TB_R;
+    const bool wide = a.CM == T2_CM;
+    const int R = wide ? T2_R : TB_R;
+    const long steps = (a.P + R - 1) / R;
     long grid = steps < target ? steps : target;
     const int spw = (int)((steps + grid - 1) / grid);
     grid = (steps + spw - 1) / spw;
+    if (wide) {
+        if (a.stats != nullptr)
+            hipLaunchKernelGGL(tail_bwd_kernel_128<true>, dim3((unsigned)grid), dim3(T2_NT), T2_LDS, st, a, spw);
+        else
+            hipLaunchKernelGGL(tail_bwd_kernel_128<false>, dim3((unsigned)grid), dim3(T2_NT), T2_LDS, st, a, spw);
+        return;
+    }
     if (a.stats != nullptr)
         hipLaunchKernelGGL(tail_bwd_kernel<true>, dim3((unsigned)grid), dim3(256), TB_LDS, st, a, spw);
     else

@@ -1,7 +1,7 @@
 """Fused bottleneck-tail backward (csrc/tail_bwd.hip) against the three kernels it replaces, on the ResNet-50 stage-1
 shape (batch 256: 802,816 pixels, 64 -> 256 channels).  Interleaved arms, median of ROUNDS.
 
-    python scripts/bench_tail.py [N] [HW]
+    python scripts/bench_tail.py [N] [HW] [CM]        (stage 2: 256 28 128)
 """
 import json
 import os
@@ -16,7 +16,8 @@ C = _ext.load()
 DEV = "cuda"
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 HW = int(sys.argv[2]) if len(sys.argv) > 2 else 56
-CM, CO = 64, 256
+CM = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+CO = 4 * CM
 ROUNDS = int(os.environ.get("ROUNDS", "20"))
 P = N * HW * HW
 

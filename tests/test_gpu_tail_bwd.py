@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
-CM, CO = 64, 256
+SHAPES = [(64, 256), (128, 512)]        # stage 1 and stage 2 of a ResNet: two kernels behind one entry point
 
 
 def _C():
@@ -29,7 +29,7 @@ def _bits(mask, shape):
     return b.to(DEV)
 
 
-def _case(N, H, W, seed, with_stats=True, with_mask=True):
+def _case(N, H, W, seed, CM, CO, with_stats=True, with_mask=True):
     C = _C()
     P = N * H * W
     dout = _bf((N, H, W, CO), 1.0, seed)
@@ -45,11 +45,11 @@ def _case(N, H, W, seed, with_stats=True, with_mask=True):
     co[4] = (torch.rand(CO, generator=g).to(DEV) - 0.5) * 0.1
     sx = _bf((N, H, W, CM), 1.0, seed + 5)
     smask = torch.randint(0, 256, (P * CM // 8,), dtype=torch.uint8, generator=g).to(DEV)
-    return dict(P=P, dout=dout, craw=craw, xin=xin, w=w, wt=wt, kout=kout, co=co, sx=sx, smask=smask)
+    return dict(P=P, CM=CM, CO=CO, dout=dout, craw=craw, xin=xin, w=w, wt=wt, kout=kout, co=co, sx=sx, smask=smask)
 
 
 def _reference(c):
-    P = c["P"]
+    P, CM, CO = c["P"], c["CM"], c["CO"]
     d = c["dout"].float().view(P, CO)
     if c["kout"] is not None:
         d = d * _bits(c["kout"], (P, CO))
@@ -63,10 +63,13 @@ def _reference(c):
     return gb, dw, dx, s, q
 
 
+@pytest.mark.parametrize("CM,CO", SHAPES)
 @pytest.mark.parametrize("N,H,W", [(1, 5, 7), (2, 14, 14), (3, 25, 27), (8, 112, 112)])
-def test_tail_bwd_matches_fp32_reference_and_the_three_kernel_sequence(N, H, W):
+def test_tail_bwd_matches_fp32_reference_and_the_three_kernel_sequence(N, H, W, CM, CO):
     C = _C()
-    c = _case(N, H, W, 100 + N)
+    if CM == 128 and N == 8:
+        H = W = 56                                   # 25,088 pixels = 1,568 tiles of 16: several tiles per workgroup
+    c = _case(N, H, W, 100 + N, CM, CO)
     P = c["P"]
     assert C.tail_bwd_ok(P, CM, CO)
     rows = 32
@@ -105,9 +108,10 @@ def test_tail_bwd_matches_fp32_reference_and_the_three_kernel_sequence(N, H, W):
     close(st[1], st0[1], "stats[1] vs dgrad epilogue", rel=5e-3)
 
 
-def test_tail_bwd_without_statistics_and_without_mask_accumulates_into_dw():
+@pytest.mark.parametrize("CM,CO", SHAPES)
+def test_tail_bwd_without_statistics_and_without_mask_accumulates_into_dw(CM, CO):
     C = _C()
-    c = _case(2, 9, 11, 7, with_mask=False)
+    c = _case(2, 9, 11, 7, CM, CO, with_mask=False)
     P = c["P"]
     dw = torch.full((CO, 1, 1, CM), 3.0, device=DEV)                    # accumulated into, not overwritten
     dx = C.tail_bwd(c["dout"], None, c["craw"], c["co"], c["xin"], c["wt"], dw)
@@ -117,10 +121,11 @@ def test_tail_bwd_without_statistics_and_without_mask_accumulates_into_dw():
     assert float((dx.float().view(P, CM) - dx_ref).abs().max()) <= 2e-2 * float(dx_ref.abs().max()) + 1e-3
 
 
-def test_tail_bwd_identity_filter_returns_g_itself():
+@pytest.mark.parametrize("CM,CO", SHAPES)
+def test_tail_bwd_identity_filter_returns_g_itself(CM, CO):
     """w = selector (dx[:, cm] = g[:, perm[cm]]): exact, so any row / column / swizzle mismatch shows."""
     C = _C()
-    c = _case(2, 16, 16, 11)
+    c = _case(2, 16, 16, 11, CM, CO)
     P = c["P"]
     perm = torch.randperm(CO, generator=torch.Generator().manual_seed(5))[:CM]
     w = torch.zeros(CO, CM)
