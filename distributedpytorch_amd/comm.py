@@ -227,7 +227,13 @@ class Communicator:
         if self.world_size > 1:
             dist.broadcast_object_list(box, src=self.to_global(0), group=self.group)
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        self.native = C.RcclComm(box[0], self.rank, self.world_size, index)
+        try:
+            self.native = C.RcclComm(box[0], self.rank, self.world_size, index)
+        except Exception as e:  # noqa: BLE001 - e.g. ncclCommInitRank refusing the topology: c10d's group still works
+            import sys
+            print(f"[comm] rank {self.global_rank}: native RCCL communicator could not be created ({type(e).__name__}: {e})",
+                  file=sys.stderr, flush=True)
+            self.native = None
         self._selftest_native(strict=False)
 
     def _selftest_native(self, strict: bool) -> None:
@@ -237,6 +243,8 @@ class Communicator:
         import time
         ok, why = True, ""
         try:
+            if self.native is None:
+                raise RuntimeError("no native communicator on this rank")
             for n in (1024, 8 * 2 ** 20):
                 t = torch.full((n,), float(self.rank + 1), dtype=torch.float32, device=self.device)
                 ticket = self.native.all_reduce(t, 0)
@@ -266,7 +274,8 @@ class Communicator:
             print(f"[comm] rank {self.global_rank}: native RCCL layer failed its self-test"
                   f"{' here (' + why + ')' if not ok else ' on another rank'}; falling back to c10d", file=sys.stderr, flush=True)
             try:
-                self.native.abort()
+                if self.native is not None:
+                    self.native.abort()
             except Exception:  # noqa: BLE001
                 pass
             self.native = None
