@@ -138,6 +138,9 @@ def save_checkpoint(path: str, module: nn.Module, optimizer=None, epoch: int = 0
     payload = {"model": sd, "optimizer": opt_sd, "epoch": epoch, "format": "torch-state_dict-v1"}
     if extra:
         payload["extra"] = extra
+    drop = getattr(module, "_drop", None)       # counter-based dropout stream of the MNIST nets: resume draws the NEXT masks
+    if drop is not None:
+        payload["dropout_step"] = int(drop.dev_step.item()) if drop.dev_step is not None else int(drop.step)
     tmp = path + ".tmp"
     torch.save(payload, tmp)
     os.replace(tmp, path)
@@ -163,4 +166,9 @@ def load_checkpoint(path: str, module: nn.Module, optimizer=None, strict: bool =
             optimizer.load_state_dict(o)
     if flat is not None:
         flat.refresh_lp()
+    drop = getattr(module, "_drop", None)
+    if drop is not None and isinstance(payload, dict) and "dropout_step" in payload:
+        drop.step = int(payload["dropout_step"])
+        if drop.dev_step is not None:
+            drop.dev_step.fill_(int(payload["dropout_step"]))
     return payload if isinstance(payload, dict) else {"model": sd}

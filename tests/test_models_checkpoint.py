@@ -123,3 +123,20 @@ def test_gpt2_tiny_cpu_and_hf_export(tmp_path):
     assert gpt2.gpt2_small().cfg.vocab_padded == 50304
     n = sum(p.numel() for p in gpt2.gpt2_small().parameters())
     assert abs(n - 124.4e6) < 0.5e6
+
+
+def test_checkpoint_carries_the_dropout_stream_position(tmp_path):
+    """the MNIST nets' counter-based dropout stream resumes where it stopped (the next masks, not the first)."""
+    import torch
+    from distributedpytorch_amd.checkpoint import save_checkpoint, load_checkpoint
+    from distributedpytorch_amd.models import mnist
+    a = mnist.Net().train()
+    x = torch.randn(4, 1, 28, 28)
+    for _ in range(3):
+        a(x)
+    assert a._drop.step == 6                      # two dropout layers per forward
+    save_checkpoint(str(tmp_path / "c.pt"), a, None, 1)
+    b = mnist.Net().train()
+    load_checkpoint(str(tmp_path / "c.pt"), b)
+    assert b._drop.step == 6
+    torch.testing.assert_close(a(x), b(x))        # same parameters, same next masks
