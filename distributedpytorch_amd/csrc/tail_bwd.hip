@@ -34,7 +34,13 @@ __device__ __forceinline__ short4v tr_read(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p));
 }
 
-__device__ __forceinline__ int xor_key(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+// XOR key of the 16-byte chunk index.  High two bits = row & 3: the four rows of a transposed read land in four
+// different 64-byte windows.  Low two bits = a permutation G of (row >> 2) & 3: the 32x32x16 row read needs ANY
+// permutation (16 rows, one chunk); the 16x16x32 row read mixes two neighbouring chunks in one 16-lane LDS group
+// (rows {0-3, 12-15} with chunk c, rows {4-11} with chunk c + 1), which needs G(0), G(3), G(1)^1, G(2)^1 distinct:
+// G = (0, 3, 2, 1) = -x & 3.  With the identity (the guide's image) that read was 2-way: SQ_LDS_BANK_CONFLICT was 43 %
+// of the stage-2 kernel's LDS cycles (profiles/pmc/tail_s2).
+__device__ __forceinline__ int xor_key(int row) { return ((row & 3) << 2) | ((0 - (row >> 2)) & 3); }
 
 constexpr int TB_R = 64;        // pixel rows per tile
 constexpr int TB_CM = 64;       // conv input channels
