@@ -127,8 +127,8 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_fwd_kernel(const u
     unsigned char* Vs = smem + TB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = (gridDim.x - 1 - blockIdx.x) * 128, qw0 = q0 + 32 * wave, q = qw0 + ql;
+    const int head = blockIdx.x, b = blockIdx.y;                    // block index slowest: see launch_fwd
+    const int q0 = (gridDim.z - 1 - blockIdx.z) * 128, qw0 = q0 + 32 * wave, q = qw0 + ql;
     const int qc = q < T ? q : T - 1;                               // rows past T: clamped loads, no stores
     const long rs = 3L * H * DH;                                    // token stride of qkv
     const unsigned short* base = qkv + (long)b * T * rs + head * DH;  // (b, t=0, q, head)
@@ -262,8 +262,8 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_kv_kernel(cons
     float* del_s = lse_s + TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kl = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int k0 = blockIdx.x * 128, kw0 = k0 + 32 * wave, key = kw0 + kl;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int k0 = blockIdx.z * 128, kw0 = k0 + 32 * wave, key = kw0 + kl;
     const int keyc = key < T ? key : T - 1;
     const long rs = 3L * H * DH, ors = (long)H * DH;
     const unsigned short* base = qkv + (long)b * T * rs + head * DH;
@@ -360,8 +360,8 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_q_kernel(const
     unsigned char* Vs = smem + TB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = (gridDim.x - 1 - blockIdx.x) * 128, qw0 = q0 + 32 * wave, q = qw0 + ql;
+    const int head = blockIdx.x, b = blockIdx.y;                    // block index slowest: see launch_fwd
+    const int q0 = (gridDim.z - 1 - blockIdx.z) * 128, qw0 = q0 + 32 * wave, q = qw0 + ql;
     const int qc = q < T ? q : T - 1;
     const long rs = 3L * H * DH, ors = (long)H * DH;
     const unsigned short* base = qkv + (long)b * T * rs + head * DH;
@@ -434,10 +434,16 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_q_kernel(const
     if (q < T) store_T<DH>(dqkv + (long)(b * T + q) * rs + head * DH, dQt, 1.f, h);
 }
 
+// Grid = (head, batch, 128-row block), the block index SLOWEST.  Workgroups go to the 8 XCDs round-robin by linear id
+// (x fastest), and under the causal mask a block's work grows with its index: with the block index on x and
+// T = 1024 (8 blocks) every XCD received ONE block index - XCD 0 all the 18-tile blocks, XCD 7 all the 2-tile ones, the
+// kernel as slow as a chip an eighth the size on the heaviest eighth.  With (head, batch) fastest every XCD sees every
+// block index equally often, heaviest blocks are dispatched first, and - 8 | H * B permitting - the blocks of one
+// (batch, head) land on one XCD, whose L2 then holds that head's K and V once.
 template <int DH>
 void launch_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, hipStream_t st) {
     const float c_log2 = (1.0f / sqrtf((float)DH)) * 1.4426950408889634f;   // 1/sqrt(DH) * log2(e)
-    hipLaunchKernelGGL(attn_fwd_kernel<DH>, dim3((T + 127) / 128, H, B), dim3(256), 0, st, (const unsigned short*)qkv,
+    hipLaunchKernelGGL(attn_fwd_kernel<DH>, dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
                        (unsigned short*)out, lse, T, H, c_log2);
 }
 
@@ -449,9 +455,9 @@ void launch_bwd(const void* qkv, const void* out, const void* dout, const float*
     const float scale = 1.0f / sqrtf((float)DH);
     hipLaunchKernelGGL(attn_delta_kernel<DH>, dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, st, (const unsigned short*)out,
                        (const unsigned short*)dout, delta, T, H, rows);
-    hipLaunchKernelGGL(attn_bwd_kv_kernel<DH>, dim3((T + 127) / 128, H, B), dim3(256), 0, st, (const unsigned short*)qkv,
+    hipLaunchKernelGGL(attn_bwd_kv_kernel<DH>, dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
                        (const unsigned short*)dout, lse, delta, (unsigned short*)dqkv, T, H, scale);
-    hipLaunchKernelGGL(attn_bwd_q_kernel<DH>, dim3((T + 127) / 128, H, B), dim3(256), 0, st, (const unsigned short*)qkv,
+    hipLaunchKernelGGL(attn_bwd_q_kernel<DH>, dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
                        (const unsigned short*)dout, lse, delta, (unsigned short*)dqkv, T, H, scale);
 }
 

@@ -107,7 +107,7 @@ std::vector<Tensor> attention_fwd(const Tensor& qkv) {
     CHECK_BF16(qkv);
     TORCH_CHECK(qkv.dim() == 5 && qkv.size(2) == 3 && (qkv.size(4) == 64 || qkv.size(4) == 128), "attention: qkv must be [B,T,3,H,64|128]");
     const int64_t B = qkv.size(0), T = qkv.size(1), H = qkv.size(3), D = qkv.size(4);
-    TORCH_CHECK(T >= 1 && B >= 1 && H >= 1 && qkv.numel() < (1ll << 31), "attention: empty or oversized problem");
+    TORCH_CHECK(T >= 1 && B >= 1 && H >= 1 && B <= 65535 && qkv.numel() < (1ll << 31), "attention: empty or oversized problem");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(qkv.device());
     Tensor out = torch::empty({B, T, H, D}, qkv.options());
     Tensor lse = torch::empty({B, H, T}, qkv.options().dtype(at::kFloat));

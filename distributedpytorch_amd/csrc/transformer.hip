@@ -55,8 +55,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const unsigned short
 // chain load -> two wave reductions -> store, i.e. one memory round trip per row per wave: with 4 waves on a CU and
 // no prefetch it ran at 42 us for 8192 x 768 (HBM time: 10 us).  Eight waves per workgroup and the NEXT row's loads
 // issued before the current row is reduced keep four times as many rows in flight without adding partial rows to fold.
-constexpr int LN_BWD_WAVES = 8;
-template <int NCH>
+template <int NCH, int LN_BWD_WAVES>
 __global__ __launch_bounds__(LN_BWD_WAVES * 64) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
                                                             const float* __restrict__ g, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, unsigned short* __restrict__ dx,
@@ -64,11 +63,13 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void layernorm_bwd_kernel(const 
                                                             long rows, int C, const unsigned short* __restrict__ addend) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = C / 8;
-    float dg[NCH][8], db[NCH][8];
+    float dg[NCH][8], db[NCH][8], gam[NCH][8];       // gamma in registers: a load inside the row loop would queue behind
+#pragma unroll                                       // the next row's prefetch (vmcnt retires in order)
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + k * 64;
 #pragma unroll
-    for (int k = 0; k < NCH; ++k)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { dg[k][j] = 0.f; db[k][j] = 0.f; }
+        for (int j = 0; j < 8; ++j) { dg[k][j] = 0.f; db[k][j] = 0.f; gam[k][j] = ch < nch ? g[ch * 8 + j] : 0.f; }
+    }
     const long rstep = (long)gridDim.x * LN_BWD_WAVES;
     long row = (long)blockIdx.x * LN_BWD_WAVES + wave;
     uint4 ndy[NCH], nx[NCH], nad[NCH];
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void layernorm_bwd_kernel(const 
                     const float h = (xv[j] - m) * rs;
                     xh[k][j] = h;
                     dg[k][j] += d[j] * h; db[k][j] += d[j];
-                    const float t = d[j] * g[ch * 8 + j];
+                    const float t = d[j] * gam[k][j];
                     gy[k][j] = t;
                     s1 += t; s2 += t * h;
                 }
@@ -166,8 +167,10 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     part += (long)blockIdx.y * rows * C;
     float* __restrict__ out = blockIdx.y == 0 ? out_a : out_b;
     float s = 0.f;
-    if (c < C)
+    if (c < C) {
+#pragma unroll 8                                       // independent loads issued together, not one round trip per row
         for (int r = rg; r < rows; r += 16) s += part[(long)r * C + c];
+    }
     red[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && c < C) {
@@ -262,8 +265,12 @@ inline int grid_for(long n) { long b = (n + 255) / 256; if (b > 4096) b = 4096; 
 
 }  // namespace
 
+// 16 waves (2 rows each, everything requested at once) needs the 128-register budget of a 1024-thread workgroup and
+// spills: 53 us against 15 us stand-alone at 8192 x 768 (scripts/bench_ln.py)
+constexpr int ln_bwd_waves() { return 8; }
+
 int layernorm_partial_rows(long rows) {
-    long b = (rows + LN_BWD_WAVES - 1) / LN_BWD_WAVES;
+    long b = (rows + ln_bwd_waves() - 1) / ln_bwd_waves();
     // one workgroup per CU.  Measured in the GPT-2 step (8192 x 768, fold on the side stream), tok/s: 128 blocks 580k,
     // 256: 624.6k, 384: 617k, 512: 620k, 1024: 616k, 2048: 599k - every extra block is another partial row to fold
     static const long cap = [] { const char* e = getenv("DPA_LN_ROWS"); return e ? atol(e) : 256L; }();
@@ -284,11 +291,13 @@ void layernorm_fwd(const void* x, const float* g, const float* b, void* y, float
 void layernorm_bwd(const void* dy, const void* x, const float* g, const float* mean, const float* rstd,
                    void* dx, float* dg_partial, float* db_partial, int partial_rows, long rows, int C, const void* addend,
                    hipStream_t st) {
-#define DPA_LN_BWD(NCH_) hipLaunchKernelGGL(layernorm_bwd_kernel<NCH_>, dim3(partial_rows), dim3(LN_BWD_WAVES * 64), 0, st, \
+#define DPA_LN_BWD_W(NCH_, W_) hipLaunchKernelGGL((layernorm_bwd_kernel<NCH_, W_>), dim3(partial_rows), dim3(W_ * 64), 0, st, \
         (const unsigned short*)dy, (const unsigned short*)x, g, mean, rstd, (unsigned short*)dx, dg_partial, db_partial, rows, C, \
         (const unsigned short*)addend)
+#define DPA_LN_BWD(NCH_) DPA_LN_BWD_W(NCH_, 8)
     if (C <= 512) DPA_LN_BWD(1); else if (C <= 1024) DPA_LN_BWD(2); else DPA_LN_BWD(4);
 #undef DPA_LN_BWD
+#undef DPA_LN_BWD_W
 }
 
 void reduce_partials(const float* partial, int rows, int C, float* out, int accumulate, hipStream_t st) {
