@@ -34,12 +34,16 @@ template <int DH> constexpr int tile_bytes() { return TILE * DH * 2; }   // 8 / 
 typedef __attribute__((address_space(3))) short4v* lds_s4_ptr;
 
 // byte offset of element (row, col) in a [64][DH] bf16 LDS image that serves row reads (ds_read_b128) and transposed
-// reads (ds_read_b64_tr_b16) alike.  DH = 64 (128-byte rows): 64-byte granules XOR-swizzled with bit 1 of the row, so
-// the 4 rows of a transposed read hit 4 distinct 64-byte windows of the 256-byte bank row.  DH = 128 (256-byte rows):
-// the 16-byte chunk index XORed with ((row & 3) << 2 | (row >> 2) & 3) - conflict-free for both kinds of read.
+// reads (ds_read_b64_tr_b16) alike.  DH = 64 (128-byte rows, two rows per 256-byte bank row): the 16-byte chunk index
+// XORed with (bit 1 of the row) << 2 | (row >> 2) & 3.  Bit 2 of the key moves rows 4m+2, 4m+3 to the other 64-byte
+// window than rows 4m, 4m+1, so the 4 rows x 64 bytes of a transposed read cover the bank row once; the low bits make
+// the 8 same-parity rows of a ds_read_b128 lane group ({0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}) use 8 different
+// chunks.  (A 64-byte-granule swizzle served the transposed reads only: PMC showed the row reads 4-way conflicted,
+// 45-59 % of the three kernels' LDS cycles - profiles/pmc/attn_*.txt.)  DH = 128 (256-byte rows): the chunk index
+// XORed with ((row & 3) << 2 | (row >> 2) & 3) - conflict-free for both kinds of read.
 template <int DH>
 __device__ __forceinline__ int img_off(int row, int col) {
-    if (DH == 64) return row * 128 + ((((col >> 5) ^ (row >> 1)) & 1) << 6) + (col & 31) * 2;
+    if (DH == 64) return row * 128 + ((((col >> 3) ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) & 7) << 4) + (col & 7) * 2;
     return row * 256 + ((((col >> 3) ^ (((row & 3) << 2) | ((row >> 2) & 3))) & 15) << 4) + (col & 7) * 2;
 }
 
