@@ -63,13 +63,11 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void layernorm_bwd_kernel(const 
                                                             long rows, int C, const unsigned short* __restrict__ addend) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = C / 8;
-    float dg[NCH][8], db[NCH][8], gam[NCH][8];       // gamma in registers: a load inside the row loop would queue behind
-#pragma unroll                                       // the next row's prefetch (vmcnt retires in order)
-    for (int k = 0; k < NCH; ++k) {
-        const int ch = lane + k * 64;
+    float dg[NCH][8], db[NCH][8];                    // (gamma copied to registers up front: measured, no difference)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { dg[k][j] = 0.f; db[k][j] = 0.f; gam[k][j] = ch < nch ? g[ch * 8 + j] : 0.f; }
-    }
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dg[k][j] = 0.f; db[k][j] = 0.f; }
     const long rstep = (long)gridDim.x * LN_BWD_WAVES;
     long row = (long)blockIdx.x * LN_BWD_WAVES + wave;
     uint4 ndy[NCH], nx[NCH], nad[NCH];
@@ -108,7 +106,7 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void layernorm_bwd_kernel(const 
                     const float h = (xv[j] - m) * rs;
                     xh[k][j] = h;
                     dg[k][j] += d[j] * h; db[k][j] += d[j];
-                    const float t = d[j] * gam[k][j];
+                    const float t = d[j] * g[ch * 8 + j];
                     gy[k][j] = t;
                     s1 += t; s2 += t * h;
                 }
@@ -291,13 +289,13 @@ void layernorm_fwd(const void* x, const float* g, const float* b, void* y, float
 void layernorm_bwd(const void* dy, const void* x, const float* g, const float* mean, const float* rstd,
                    void* dx, float* dg_partial, float* db_partial, int partial_rows, long rows, int C, const void* addend,
                    hipStream_t st) {
-#define DPA_LN_BWD_W(NCH_, W_) hipLaunchKernelGGL((layernorm_bwd_kernel<NCH_, W_>), dim3(partial_rows), dim3(W_ * 64), 0, st, \
+#define DPA_LN_BWD_H(NCH_, W_) hipLaunchKernelGGL((layernorm_bwd_kernel<NCH_, W_>), dim3(partial_rows), dim3(W_ * 64), 0, st, \
         (const unsigned short*)dy, (const unsigned short*)x, g, mean, rstd, (unsigned short*)dx, dg_partial, db_partial, rows, C, \
         (const unsigned short*)addend)
-#define DPA_LN_BWD(NCH_) DPA_LN_BWD_W(NCH_, 8)
+#define DPA_LN_BWD(NCH_) DPA_LN_BWD_H(NCH_, 8)
     if (C <= 512) DPA_LN_BWD(1); else if (C <= 1024) DPA_LN_BWD(2); else DPA_LN_BWD(4);
 #undef DPA_LN_BWD
-#undef DPA_LN_BWD_W
+#undef DPA_LN_BWD_H
 }
 
 void reduce_partials(const float* partial, int rows, int C, float* out, int accumulate, hipStream_t st) {
