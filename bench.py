@@ -179,7 +179,7 @@ def main():
             model = mnist.Net().to(device).train()
             x, y = synthetic_batch("mnist", batch, device, seed=1234 + rank)
             lr, momentum, wd, use_lp = 0.01, 0.5, 0.0, False
-            loss_fn = lambda: mnist.nll_loss(model(x), y)  # noqa: E731
+            loss_fn = lambda: model.loss(x, y)  # noqa: E731   (head + log-softmax + NLL fused: models/mnist.py)
             items = batch
             flops_item = 3.0 * 2.0 * 480500.0           # 480,500 MACs forward per sample, x3 for fwd + bwd
             cfg = {"model": "mnist_cnn", "global_batch": batch * world, "image": "1x28x28"}
@@ -200,7 +200,7 @@ def main():
             # the single gradient all-reduce and the fused optimizer kernel stay outside the graph
             from distributedpytorch_amd.parallel.graph import GraphedStep
             model._drop.use_device_counter(device)
-            graphed = GraphedStep(dp, lambda xx, yy: mnist.nll_loss(model(xx), yy), (x, y), after_backward=model._drop.advance)
+            graphed = GraphedStep(dp, lambda xx, yy: model.loss(xx, yy), (x, y))   # Net.loss bumps the dropout counter itself
             cfg["hipgraph"] = True
 
         from distributedpytorch_amd.metrics import PhaseTimer

@@ -862,7 +862,40 @@ std::vector<Tensor> linear_f32_bwd(const Tensor& x, const Tensor& w, const Tenso
     if (need_dx) dx = torch::empty_like(x);
     dpa::linear_f32_bwd(x.data_ptr<float>(), w.data_ptr<float>(), y.data_ptr<float>(), dy.data_ptr<float>(),
                         need_dx ? dx.data_ptr<float>() : nullptr, dw.data_ptr<float>(), db.data_ptr<float>(), x.size(0),
-                        x.size(1), w.size(0), relu, (float)gscale, lsm, acc_w, cur_stream());
+                        x.size(1), w.size(0), relu, (float)gscale, lsm, acc_w, nullptr, cur_stream());
+    return {dx, dw, db};
+}
+
+// The classifier head with its loss: (loss [], logp [rows, out]) = (mean NLL, log_softmax(x @ w^T + b)) in one launch.
+// `step`: the dropout stream's device counter, incremented here (models/mnist.py) - or None.
+std::vector<Tensor> linear_lsm_nll_fwd(const Tensor& x, const Tensor& w, const Tensor& b, const Tensor& target,
+                                       const c10::optional<Tensor>& step) {
+    CHECK_F32(x); CHECK_F32(w); CHECK_F32(b); CHECK_I64(target);
+    TORCH_CHECK(x.dim() == 2 && w.dim() == 2 && w.size(1) == x.size(1) && b.numel() == w.size(0) && w.size(0) <= 16 &&
+                x.size(1) <= 448 && target.numel() == x.size(0) && x.size(0) >= 1, "linear_lsm_nll: shapes (out <= 16, in <= 448)");
+    Guard g(x);
+    Tensor logp = torch::empty({x.size(0), w.size(0)}, x.options()), loss = torch::empty({}, x.options());
+    dpa::linear_lsm_nll_fwd(x.data_ptr<float>(), w.data_ptr<float>(), b.data_ptr<float>(), target.data_ptr<int64_t>(),
+                            logp.data_ptr<float>(), loss.data_ptr<float>(), const_cast<int64_t*>(step_ptr(step)), x.size(0),
+                            x.size(1), w.size(0), cur_stream());
+    return {loss, logp};
+}
+
+// its backward: log-softmax, mean-NLL and the Linear's dx | dw | db in one launch; gloss = the scalar loss gradient
+std::vector<Tensor> linear_lsm_nll_bwd(const Tensor& x, const Tensor& w, const Tensor& logp, const Tensor& gloss, const Tensor& target,
+                                       bool need_dx, const c10::optional<Tensor>& dw_acc, const c10::optional<Tensor>& db_acc) {
+    CHECK_F32(x); CHECK_F32(w); CHECK_F32(logp); CHECK_F32(gloss); CHECK_I64(target);
+    TORCH_CHECK(gloss.numel() == 1 && logp.size(0) == x.size(0) && logp.size(1) == w.size(0) && w.size(0) <= 16 &&
+                target.numel() == x.size(0), "linear_lsm_nll bwd: shapes");
+    Guard g(x);
+    Tensor dw, db, dx; bool acc_w, acc_b;
+    grad_dst(dw_acc, w, false, dw, acc_w);
+    grad_dst(db_acc, torch::empty({w.size(0)}, w.options()), false, db, acc_b);
+    TORCH_CHECK(acc_w == acc_b, "linear_lsm_nll bwd: pass both accumulators or neither");
+    if (need_dx) dx = torch::empty_like(x);
+    dpa::linear_f32_bwd(x.data_ptr<float>(), w.data_ptr<float>(), logp.data_ptr<float>(), gloss.data_ptr<float>(),
+                        need_dx ? dx.data_ptr<float>() : nullptr, dw.data_ptr<float>(), db.data_ptr<float>(), x.size(0),
+                        x.size(1), w.size(0), false, 1.f, 2, acc_w, target.data_ptr<int64_t>(), cur_stream());
     return {dx, dw, db};
 }
 
@@ -976,6 +1009,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("conv5_pool_relu_bwd", &conv5_pool_relu_bwd);
     m.def("linear_f32_fwd", &linear_f32_fwd);
     m.def("linear_f32_bwd", &linear_f32_bwd);
+    m.def("linear_lsm_nll_fwd", &linear_lsm_nll_fwd);
+    m.def("linear_lsm_nll_bwd", &linear_lsm_nll_bwd);
     m.def("log_softmax_fwd", &log_softmax_fwd);
     m.def("log_softmax_bwd", &log_softmax_bwd);
     m.def("nll_fwd", &nll_fwd);

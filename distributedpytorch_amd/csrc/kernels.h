@@ -210,8 +210,14 @@ void linear_f32_fwd(const float* x, const float* w, const float* b, float* y, in
 void linear_lsm_fwd(const float* x, const float* w, const float* b, float* logp, int rows, int in, int out, hipStream_t st);
 // one launch: dx (may be nullptr) | dw, db (overwritten, or added to with accumulate).  lsm: y holds log-probabilities and
 // dy is the gradient w.r.t. them (log-softmax backward in line); else relu / gscale as for the conv
+// lsm: 0 plain, 1 y = log-probabilities and dy their gradient, 2 additionally the mean-NLL backward: dy = ONE float (the
+// loss gradient), tgt = the targets (out <= 16 only)
 void linear_f32_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* db,
-                    int rows, int in, int out, int relu, float gscale, int lsm, int accumulate, hipStream_t st);
+                    int rows, int in, int out, int relu, float gscale, int lsm, int accumulate, const int64_t* tgt, hipStream_t st);
+// logp = log_softmax(x @ w^T + b), loss = -mean_r logp[r][t_r] in one single-workgroup launch (out <= 16, in <= 448: LDS);
+// step (optional): device counter incremented by one
+void linear_lsm_nll_fwd(const float* x, const float* w, const float* b, const int64_t* t, float* logp, float* loss,
+                        int64_t* step, int rows, int in, int out, hipStream_t st);
 void log_softmax_fwd(const float* x, float* y, int rows, int V, hipStream_t st);
 void log_softmax_bwd(const float* dy, const float* y, float* dx, int rows, int V, hipStream_t st);
 void nll_fwd(const float* logp, const int64_t* t, float* loss, int rows, int V, hipStream_t st);

@@ -311,9 +311,68 @@ __global__ __launch_bounds__(256) void linear_lsm_fwd_kernel(const float* __rest
     if (lane < out) logp[(long)row * out + lane] = v - m - __logf(s);
 }
 
+// The classifier head and its loss in ONE single-workgroup launch (out <= 16):  logp = log_softmax(x @ w^T + b),
+// loss = -mean_r logp[r][t_r]  (reference DP.py:94-95,152 - three framework calls, here one kernel; the loss needs no
+// atomics and no zeroed accumulator because one workgroup sees every row).  16 lanes = one row, lane = class; x and w are
+// staged through LDS with one batch of independent loads (x was written by the previous kernel, possibly on another XCD:
+// ~2 us per DEPENDENT step), in row chunks of `chunk` rows.  `step` (optional): the device-resident dropout step counter
+// of models/mnist.py, bumped here - this is the last forward kernel, every reader of the counter has run - so a replayed
+// hipGraph needs no one-thread kernel for it.
+__global__ __launch_bounds__(1024) void linear_lsm_nll_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                  const float* __restrict__ b, const int64_t* __restrict__ t,
+                                                                  float* __restrict__ logp, float* __restrict__ loss,
+                                                                  int64_t* step, int rows, int in, int out, int chunk) {
+    extern __shared__ float lsm_smem[];
+    float* ws = lsm_smem;                       // [16][in]
+    float* xs = lsm_smem + 16 * in;             // [chunk][in]
+    const int tid = threadIdx.x, cls = tid & 15, rsub = tid >> 4;
+    for (int i = tid; i < out * in; i += 1024) ws[i] = w[i];
+    float lacc = 0.f;
+    for (int r0 = 0; r0 < rows; r0 += chunk) {
+        const int nr = rows - r0 < chunk ? rows - r0 : chunk;
+        __syncthreads();
+        for (int i = tid; i < nr * in; i += 1024) xs[i] = x[(long)r0 * in + i];
+        __syncthreads();
+        for (int rl = rsub; rl < nr; rl += 64) {          // a 16-lane group stays together: the shuffles below are safe
+            float v = -INFINITY;
+            if (cls < out) {
+                float acc = b != nullptr ? b[cls] : 0.f;
+                const float* xr = xs + rl * in;
+                const float* wr = ws + cls * in;
+                for (int k = 0; k < in; ++k) acc += xr[k] * wr[k];
+                v = acc;
+            }
+            float m = v;
+            m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64));
+            m = fmaxf(m, __shfl_xor(m, 4, 64)); m = fmaxf(m, __shfl_xor(m, 8, 64));
+            float e = cls < out ? __expf(v - m) : 0.f;
+            e += __shfl_xor(e, 1, 64); e += __shfl_xor(e, 2, 64); e += __shfl_xor(e, 4, 64); e += __shfl_xor(e, 8, 64);
+            const long r = r0 + rl;
+            if (cls < out) {
+                const float lp = v - m - __logf(e);
+                logp[r * out + cls] = lp;
+                if ((int64_t)cls == t[r]) lacc -= lp;
+            }
+        }
+    }
+    lacc = wave_reduce_sum(lacc);
+    __shared__ float red[16];
+    if ((tid & 63) == 0) red[tid >> 6] = lacc;
+    __syncthreads();
+    if (tid == 0) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum += red[i];
+        loss[0] = sum / (float)rows;
+        if (step != nullptr) step[0] += 1;
+    }
+}
+
 // Upstream gradient of a Linear's pre-activation, element (r, o):
 //   plain:  g = dy * (relu ? (y > 0) * gscale : 1)          (y = the layer's stored output; gscale = 1/(1-p) of a dropout behind it)
-//   lsm:    g = dy - exp(y) * sum_c dy[r][c]                 (y = log-probabilities: log-softmax backward in line)
+//   lsm 1:  g = dy - exp(y) * sum_c dy[r][c]                 (y = log-probabilities: log-softmax backward in line)
+//   lsm 2:  g = (exp(y) - [o == t_r]) * g0 / rows            (log-softmax AND mean-NLL backward in line: dy = the scalar
+//                                                             loss gradient g0, t = the targets; no row sum to fetch)
 // These loops are LATENCY-bound (a few hundred loads per thread, one wave per SIMD): every helper below issues its loads
 // in independent batches of 8 before anything consumes them - a runtime-trip-count loop with one load per iteration
 // costs one L2 round trip per iteration (measured: 40 us for the 128 x 10 head, 18 us for the 128 x 50 layer).
@@ -340,7 +399,8 @@ __device__ __forceinline__ float lin_rowsum(const float* __restrict__ dy, long r
     }
     return s;
 }
-__device__ __forceinline__ float lin_g1(float dyv, float yv, int relu, float gscale, int lsm, float rowsum) {
+__device__ __forceinline__ float lin_g1(float dyv, float yv, int relu, float gscale, int lsm, float rowsum, bool hit = false) {
+    if (lsm == 2) return (__expf(yv) - (hit ? 1.f : 0.f)) * rowsum;      // rowsum carries g0 / rows
     if (lsm) return dyv - __expf(yv) * rowsum;
     if (relu) return yv > 0.f ? dyv * gscale : 0.f;
     return dyv;
@@ -354,25 +414,27 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ y, const float* __restrict__ dy,
                                                          float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
                                                          int rows, int in, int out, int relu, float gscale, int lsm,
-                                                         int accumulate, int dx_blocks) {
+                                                         int accumulate, int dx_blocks, const int64_t* __restrict__ tgt) {
+    const float gs = lsm == 2 ? dy[0] / (float)rows : 0.f;
     if ((int)blockIdx.x < dx_blocks) {
         const long total = (long)rows * in;
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)dx_blocks * 256) {
             const int k = (int)(i % in); const long r = i / in;
-            const float rs = lsm ? lin_rowsum<NARROW>(dy, r, out) : 0.f;
+            const float rs = lsm == 1 ? lin_rowsum<NARROW>(dy, r, out) : gs;
             float acc = 0.f;
             if (NARROW) {
                 float dv[16], yv[16], wv[16];
+                const int tr = lsm == 2 ? (int)tgt[r] : -1;
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const bool ok = u < out;
                     const long e = r * out + (ok ? u : 0);
-                    dv[u] = ok ? dy[e] : 0.f;
+                    dv[u] = (ok && lsm != 2) ? dy[e] : 0.f;
                     yv[u] = (relu || lsm) ? y[e] : 1.f;
                     wv[u] = ok ? w[(long)u * in + k] : 0.f;
                 }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) acc += (u < out ? lin_g1(dv[u], yv[u], relu, gscale, lsm, rs) : 0.f) * wv[u];
+                for (int u = 0; u < 16; ++u) acc += (u < out ? lin_g1(dv[u], yv[u], relu, gscale, lsm, rs, u == tr) : 0.f) * wv[u];
                 dx[i] = acc;
                 continue;
             }
@@ -400,19 +462,21 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict
     float acc = 0.f, bs = 0.f;
     for (int r = rg; r < rows; r += 32) {
         float dv[8], yv[8], xv[8], rs[8];
+        int tr[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const long rr = r + 4 * u;
             const bool ok = rr < rows;
             const long e = (ok ? rr : 0) * out + o;
-            dv[u] = ok ? dy[e] : 0.f;
+            dv[u] = (ok && lsm != 2) ? dy[e] : 0.f;
             yv[u] = (relu || lsm) ? y[e] : 1.f;
             xv[u] = (ok && kok) ? x[rr * in + k] : 0.f;
-            rs[u] = (lsm && ok) ? lin_rowsum<NARROW>(dy, rr, out) : 0.f;
+            rs[u] = (lsm == 1 && ok) ? lin_rowsum<NARROW>(dy, rr, out) : gs;
+            tr[u] = (lsm == 2 && ok) ? (int)tgt[rr] : -1;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const float g = r + 4 * u < rows ? lin_g1(dv[u], yv[u], relu, gscale, lsm, rs[u]) : 0.f;
+            const float g = r + 4 * u < rows ? lin_g1(dv[u], yv[u], relu, gscale, lsm, rs[u], tr[u] == o) : 0.f;
             acc += g * xv[u]; bs += g;
         }
     }
@@ -526,16 +590,29 @@ void linear_lsm_fwd(const float* x, const float* w, const float* b, float* logp,
     hipLaunchKernelGGL(linear_lsm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, w, b, logp, rows, in, out);
 }
 
+int linear_lsm_nll_chunk(int rows, int in) {               // rows of x staged per pass: 32 KiB of LDS
+    int c = 8192 / (in > 0 ? in : 1);
+    if (c > rows) c = rows;
+    return c < 1 ? 1 : c;
+}
+
+void linear_lsm_nll_fwd(const float* x, const float* w, const float* b, const int64_t* t, float* logp, float* loss,
+                        int64_t* step, int rows, int in, int out, hipStream_t st) {
+    const int chunk = linear_lsm_nll_chunk(rows, in);
+    const size_t lds = (size_t)(16 + chunk) * in * sizeof(float);
+    hipLaunchKernelGGL(linear_lsm_nll_fwd_kernel, dim3(1), dim3(1024), lds, st, x, w, b, t, logp, loss, step, rows, in, out, chunk);
+}
+
 void linear_f32_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* db,
-                    int rows, int in, int out, int relu, float gscale, int lsm, int accumulate, hipStream_t st) {
+                    int rows, int in, int out, int relu, float gscale, int lsm, int accumulate, const int64_t* tgt, hipStream_t st) {
     const int dxb = dx != nullptr ? grid_for((long)rows * in) : 0;
     const int dwb = out * ((in + 63) / 64);
     if (out <= 16)
         hipLaunchKernelGGL(linear_bwd_kernel<true>, dim3((unsigned)(dxb + dwb)), dim3(256), 0, st, x, w, y, dy, dx, dw, db, rows, in,
-                           out, relu, gscale, lsm, accumulate, dxb);
+                           out, relu, gscale, lsm, accumulate, dxb, tgt);
     else
         hipLaunchKernelGGL(linear_bwd_kernel<false>, dim3((unsigned)(dxb + dwb)), dim3(256), 0, st, x, w, y, dy, dx, dw, db, rows, in,
-                           out, relu, gscale, lsm, accumulate, dxb);
+                           out, relu, gscale, lsm, accumulate, dxb, tgt);
 }
 
 void log_softmax_fwd(const float* x, float* y, int rows, int V, hipStream_t st) {

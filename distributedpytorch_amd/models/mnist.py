@@ -38,6 +38,7 @@ class _DropState:
         return self.step * 1_000_003 + layer
 
     def advance(self) -> None:
+        """End of a step whose loss did NOT go through ``Net.loss`` (that kernel bumps the device counter itself)."""
         if self.dev_step is not None:
             from ..ops import _ext
             _ext.load().counter_add(self.dev_step, 1)
@@ -74,6 +75,14 @@ class Net(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return ops.linear_log_softmax(self.hidden(x), self.fc2.weight, self.fc2.bias)
 
+    def loss(self, x: torch.Tensor, target: torch.Tensor, return_output: bool = False):
+        """``F.nll_loss(self(x), target)`` (reference DP.py:151-152) with the head, the log-softmax and the loss in one
+        kernel each way.  In training with a device-resident dropout counter that kernel also closes the step's dropout
+        stream, so callers of ``loss`` do NOT call ``_drop.advance()``."""
+        bump = self._drop.dev_step if self.training else None
+        loss, logp = ops.linear_log_softmax_nll(self.hidden(x), self.fc2.weight, self.fc2.bias, target, bump)
+        return (loss, logp) if return_output else loss
+
 
 class Net1(nn.Module):
     """Model-parallel stage 0: the two conv blocks, no dropout (reference MP.py:76-88)."""
@@ -100,6 +109,12 @@ class Net2(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = ops.linear_f32(x, self.fc1.weight, self.fc1.bias, relu=True)
         return ops.linear_log_softmax(x, self.fc2.weight, self.fc2.bias)
+
+    def loss(self, x: torch.Tensor, target: torch.Tensor, return_output: bool = False):
+        """Last pipeline stage: activations in, loss out (reference MP.py:158-160), head and loss fused as in ``Net.loss``."""
+        h = ops.linear_f32(x, self.fc1.weight, self.fc1.bias, relu=True)
+        loss, logp = ops.linear_log_softmax_nll(h, self.fc2.weight, self.fc2.bias, target)
+        return (loss, logp) if return_output else loss
 
 
 def nll_loss(log_probs: torch.Tensor, target: torch.Tensor) -> torch.Tensor:

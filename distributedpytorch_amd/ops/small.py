@@ -128,6 +128,42 @@ def linear_log_softmax(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> tor
     return log_softmax(linear_f32(x, w, b))
 
 
+class _LinearNllFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, target, bump):
+        loss, logp = _ext.load().linear_lsm_nll_fwd(x, w.detach(), b.detach(), target, bump)
+        ctx.save_for_backward(x, logp, target)
+        ctx.w, ctx.b = w, b
+        ctx.mark_non_differentiable(logp)
+        return loss, logp
+
+    @staticmethod
+    def backward(ctx, gloss, _glogp):
+        x, logp, target = ctx.saved_tensors
+        w, b = ctx.w, ctx.b
+        tw, tb = _sink_pair(w, b)
+        dx, dw, db = _ext.load().linear_lsm_nll_bwd(x, w.detach(), logp, gloss.reshape(1).contiguous(), target,
+                                                    ctx.needs_input_grad[0], tw, tb)
+        if tw is not None:
+            _sink.ready(w); _sink.ready(b)
+            dw = db = None
+        return (dx if ctx.needs_input_grad[0] else None), dw, db, None, None
+
+
+def linear_log_softmax_nll(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, target: torch.Tensor,
+                           bump: Optional[torch.Tensor] = None):
+    """``(F.nll_loss(log_softmax(x @ w^T + b), target), log_probs)`` - the reference's classifier head and its loss
+    (DP.py:94-95,152) as ONE kernel forward and ONE backward (log-softmax, NLL, dx | dw | db).  ``log_probs`` comes back
+    for accuracy counting and carries no gradient.  ``bump``: a device int64 counter incremented by the forward kernel
+    (the dropout stream of ``models.mnist``: saves a one-thread launch per replayed step)."""
+    if _ext.use_hip(x) and w.shape[0] <= 16 and w.shape[1] <= 448:
+        return _LinearNllFn.apply(x.contiguous(), w, b, target.contiguous(), bump)
+    logp = linear_log_softmax(x, w, b)
+    if bump is not None:
+        bump += 1
+    return nll_loss(logp, target), logp.detach()
+
+
 class _DropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mask):

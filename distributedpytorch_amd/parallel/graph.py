@@ -36,16 +36,19 @@ class GraphedStep:
         with torch.cuda.stream(side):                      # warm up allocator pools / lazy init off the capture
             for _ in range(warmup):
                 with engine.no_sync():
-                    loss_fn(*self.static_inputs).backward()
+                    loss = loss_fn(*self.static_inputs)
+                    loss.backward()
                 if after_backward is not None:
                     after_backward()
+            # the seed gradient of backward(): allocated once here, not filled by a kernel of its own at every replay
+            self._seed = torch.ones_like(loss)
             engine.flat.grad.zero_()                       # warm-up gradients are discarded
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()                # hipGraph on ROCm
         with torch.cuda.graph(self.graph):
             with engine.no_sync():
                 self.static_loss = loss_fn(*self.static_inputs)
-                self.static_loss.backward()
+                self.static_loss.backward(self._seed)
             if after_backward is not None:
                 after_backward()
         engine.flat.grad.zero_()                           # capture does not execute, but keep the invariant explicit

@@ -43,7 +43,7 @@ def build_model(name: str):
     if name == "mnist_cnn":
         from .models import mnist
         m = mnist.Net()
-        return m, "mnist", (lambda mod, x, y: mnist.nll_loss(mod(x), y)), False, 10
+        return m, "mnist", (lambda mod, x, y: mod.loss(x, y)), False, 10
     if name in ("resnet50", "resnet101", "resnet152", "tiny_resnet"):
         from .models import resnet
         m = getattr(resnet, name)()
@@ -118,8 +118,8 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
             x0, y0 = dataset.batch(list(range(min(int(bsz), len(dataset)))))
             if x0.shape[0] == int(bsz):
                 model._drop.use_device_counter(device)
-                graphed = GraphedStep(dp, lambda a, b: loss_fn(model, a, b), (x0.to(device), y0.to(device)),
-                                      after_backward=model._drop.advance)
+                # (Net.loss's kernel bumps the device-resident dropout counter: no after_backward hook)
+                graphed = GraphedStep(dp, lambda a, b: loss_fn(model, a, b), (x0.to(device), y0.to(device)))
         accum = max(1, cfg.accum_steps)
         if accum > 1:
             graphed = None                                   # (the captured step has no accumulate-only variant)

@@ -369,6 +369,48 @@ def test_mnist_fused_head_dropout_and_gradient_sink_match_torch():
     _close(lp, F.log_softmax(F.linear(hr, ref["fc2.weight"], ref["fc2.bias"]), dim=1).detach(), 1e-4, 1e-4, "eval log-probs")
 
 
+def test_mnist_fused_head_loss_matches_unfused_path_and_torch():
+    """``Net.loss`` (head + log-softmax + mean NLL: one kernel forward, one backward - csrc/smallnet.hip
+    ``linear_lsm_nll_fwd_kernel`` and ``linear_bwd_kernel``'s lsm = 2 mode) against ``nll_loss(net(x))`` through the
+    separate ops and against stock torch fp32; ragged row counts; the device dropout counter is bumped by the forward
+    kernel exactly once per call."""
+    from distributedpytorch_amd import ops
+    from distributedpytorch_amd.models import mnist
+    torch.manual_seed(3)
+    for rows, inn, out in ((128, 50, 10), (37, 50, 10), (200, 320, 16), (1, 7, 3)):
+        h = torch.randn(rows, inn, device=DEV, requires_grad=True)
+        w = (torch.randn(out, inn, device=DEV) * 0.2).requires_grad_()
+        b = torch.randn(out, device=DEV, requires_grad=True)
+        t = torch.randint(0, out, (rows,), device=DEV)
+        ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+        loss, logp = ops.linear_log_softmax_nll(h, w, b, t, ctr)
+        assert not logp.requires_grad
+        (loss * 3.0).backward()
+        hr, wr, br = (v.detach().cpu().double().requires_grad_() for v in (h, w, b))
+        lpr = F.log_softmax(F.linear(hr, wr, br), dim=1)
+        lossr = F.nll_loss(lpr, t.cpu())
+        (lossr * 3.0).backward()
+        _close(loss, lossr.float(), 1e-5, 1e-5, f"fused loss {rows}x{inn}x{out}")
+        _close(logp, lpr.detach().float(), 1e-5, 1e-5, "log-probs")
+        _close(h.grad, hr.grad.float(), 1e-4, 1e-6, "grad h")
+        _close(w.grad, wr.grad.float(), 1e-4, 1e-6, "grad w")
+        _close(b.grad, br.grad.float(), 1e-4, 1e-6, "grad b")
+        assert int(ctr.item()) == 1
+    # whole net: fused loss == separate ops, same dropout draws (host counter rewound between the two)
+    net = mnist.Net(seed=5).to(DEV).train()
+    x = torch.randn(64, 1, 28, 28, device=DEV)
+    t = torch.randint(0, 10, (64,), device=DEV)
+    net._drop.step = 10
+    l1 = net.loss(x, t); l1.backward()
+    g1 = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad(set_to_none=True)
+    net._drop.step = 10
+    l2 = mnist.nll_loss(net(x), t); l2.backward()
+    _close(l1, l2, 1e-6, 1e-6, "Net.loss vs nll_loss(net(x))")
+    for a, p in zip(g1, net.parameters()):
+        _close(a, p.grad, 1e-4, 1e-6, "Net.loss grads")
+
+
 def test_lm_head_shaped_linear_matches_fp32_reference_on_both_gemm_kernels():
     """ops.linear on an LM-head-shaped problem (wide vocabulary, nothing fused): forward, input gradient and weight
     gradient against the fp32 expression, once through csrc/gemm_wide.hip (forced) and once through the 128 x 128

@@ -46,6 +46,20 @@ def test_net_matches_stock_and_state_dict_is_interchangeable(tmp_path):
     ck.load_checkpoint(path, ours)
 
 
+def test_net_loss_equals_nll_of_forward_on_cpu():
+    """``Net.loss`` / ``Net2.loss`` (fused head + loss on the GPU) fall back to the separate ops on the CPU."""
+    torch.manual_seed(0)
+    net = mnist.Net().eval()
+    x, t = torch.randn(9, 1, 28, 28), torch.randint(0, 10, (9,))
+    loss, logp = net.loss(x, t, return_output=True)
+    assert torch.allclose(loss, F.nll_loss(net(x), t), atol=1e-6) and torch.allclose(logp, net(x), atol=1e-6)
+    n2 = mnist.Net2()
+    h = torch.randn(9, 320)
+    assert torch.allclose(n2.loss(h, t), F.nll_loss(n2(h), t), atol=1e-6)
+    loss = net.loss(x, t); loss.backward()
+    assert all(p.grad is not None for p in net.parameters())
+
+
 def test_mp_stage_keys_union_is_dp_key_set():
     k1, k2 = set(mnist.Net1().state_dict()), set(mnist.Net2().state_dict())
     assert k1 | k2 == set(mnist.Net().state_dict()) and not (k1 & k2)
