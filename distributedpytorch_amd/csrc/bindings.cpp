@@ -980,6 +980,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("dbias") = py::none());
     m.def("transpose_filter", &transpose_filter);
     m.def("transpose_filters_batched", &transpose_filters_batched);
+    m.def("transpose_tile", [] { return dpa::transpose_tile(); });
     m.def("colsum", &colsum);
     m.def("bn_stats", &bn_stats);
     m.def("bn_finalize", &bn_finalize);

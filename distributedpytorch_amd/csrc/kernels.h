@@ -96,6 +96,7 @@ void tail_bwd(const TailBwdArgs& a, hipStream_t st);
 void transpose_filter(const void* w, void* wt, int K, int RS, int C, hipStream_t st);
 // all filters of a model in one launch; table [nconv][6] int64 on device = (src off, dst off, K, RS, C, first tile)
 void transpose_filters_batched(const void* src, void* dst, const long* table, int nconv, long total_tiles, hipStream_t st);
+int transpose_tile();   // tile edge the table's tile counts are made of
 // column sums of a bf16 [M, K] matrix into fp32 [K] (bias gradient), accumulates.
 // wide matrices (K > 2048) need a [colsum_workspace_rows][K] fp32 scratch buffer
 int colsum_workspace_rows(long M, int K);

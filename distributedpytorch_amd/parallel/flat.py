@@ -76,6 +76,8 @@ class FlatParams:
         self._tr_table = None
         self._tr_tiles = 0
         if self.lp is not None:
+            from ..ops import _ext
+            tt = _ext.load().transpose_tile()       # tile edge of csrc/conv_igemm.hip's batched transpose
             rows, tiles, done = [], 0, set()
             for mod in module.modules():
                 for pname in self._twin_names(mod):
@@ -88,7 +90,7 @@ class FlatParams:
                     done.add(id(w))                 # a tied matrix (GPT-2 wte) is transposed once
                     K, R, S, C = w.shape if w.dim() == 4 else (w.shape[0], 1, 1, w.shape[1])   # Linear [out,in] = K,1,1,C
                     rows.append([offsets[i], offsets[i], K, R * S, C, tiles])
-                    tiles += ((K + 31) // 32) * ((C + 31) // 32) * R * S
+                    tiles += ((K + tt - 1) // tt) * ((C + tt - 1) // tt) * R * S
             if rows:
                 self.lp_t = torch.zeros(self.total, dtype=self.lp_dtype, device=device)
                 self._tr_table = torch.tensor(rows, dtype=torch.int64, device=device)

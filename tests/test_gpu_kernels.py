@@ -411,6 +411,47 @@ def test_mnist_fused_head_loss_matches_unfused_path_and_torch():
         _close(a, p.grad, 1e-4, 1e-6, "Net.loss grads")
 
 
+def test_batched_filter_transpose_matches_permute_on_every_twin():
+    """``FlatParams.refresh_transposed`` (ONE launch of ``transpose_filters_batched_kernel`` for the whole model, 64 x 64
+    tiles, 16-byte path and scalar path) against ``permute`` of the bf16 shadow, for every layer that has a transposed twin:
+    conv filters [K,R,S,C] -> [C,R,S,K] of a ResNet (7x7 stem, 3x3, 1x1, the 1000-way head) and GPT-2's Linear weights and
+    tied embedding matrix; plus a table of odd shapes straight through the kernel."""
+    from distributedpytorch_amd.models import resnet, gpt2
+    from distributedpytorch_amd.parallel.flat import FlatParams
+    C_ = _C()
+    for model in (resnet.tiny_resnet(), gpt2.gpt2_tiny(n_layer=1, n_embd=64, n_head=2, vocab=1000, n_positions=64)):
+        model = model.to(DEV)
+        flat = FlatParams(model)
+        assert flat.lp_t is not None
+        seen = 0
+        for mod in model.modules():
+            for pname in FlatParams._twin_names(mod):
+                w = getattr(mod, pname, None)
+                twin = getattr(mod, pname + "_lp_t", None)
+                if w is None or twin is None:
+                    continue
+                a, b = flat.slice_of(w)
+                shadow = flat.lp[a:b].view(w.shape)
+                ref = shadow.permute(3, 1, 2, 0) if w.dim() == 4 else shadow.t()
+                assert torch.equal(twin, ref.contiguous()), (type(mod).__name__, pname, tuple(w.shape))
+                seen += 1
+        assert seen >= 3
+    # odd shapes: K, C not multiples of 8 (scalar path), ragged tiles, misaligned offsets
+    shapes = [(70, 1, 130), (64, 9, 64), (13, 4, 5), (200, 1, 72), (8, 1, 8)]
+    offs, rows, tiles, tt = 3, [], 0, C_.transpose_tile()          # start misaligned on purpose
+    for K, RS, Cc in shapes:
+        rows.append([offs, offs, K, RS, Cc, tiles])
+        tiles += -(-K // tt) * -(-Cc // tt) * RS
+        offs += K * RS * Cc
+        offs += (-offs) % 8 if K % 8 == 0 and Cc % 8 == 0 else 1
+    src = torch.randn(offs + 64, device=DEV).to(torch.bfloat16)
+    dst = torch.zeros_like(src)
+    C_.transpose_filters_batched(src, dst, torch.tensor(rows, dtype=torch.int64, device=DEV), tiles)
+    for (o, _, K, RS, Cc, _t) in rows:
+        ref = src[o:o + K * RS * Cc].view(K, RS, Cc).permute(2, 1, 0).contiguous()
+        assert torch.equal(dst[o:o + K * RS * Cc].view(Cc, RS, K), ref), (K, RS, Cc)
+
+
 def test_lm_head_shaped_linear_matches_fp32_reference_on_both_gemm_kernels():
     """ops.linear on an LM-head-shaped problem (wide vocabulary, nothing fused): forward, input gradient and weight
     gradient against the fp32 expression, once through csrc/gemm_wide.hip (forced) and once through the 128 x 128
