@@ -229,30 +229,6 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_fwd_kernel(const u
     }
 }
 
-// ------------------------------------------------------------------------------ delta = rowsum(dO * O)
-template <int DH>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const unsigned short* __restrict__ o, const unsigned short* __restrict__ d_o,
-                                                         float* __restrict__ delta, int T, int H, long rows) {
-    // one (DH / 8)-lane group per (b, t, head) row of DH elements
-    constexpr int LPR = DH / 8;
-    const long row = (long)blockIdx.x * (256 / LPR) + (threadIdx.x / LPR);
-    const int c = threadIdx.x % LPR;
-    float s = 0.f;
-    if (row < rows) {
-        uint4 a = *(const uint4*)(o + row * DH + c * 8), g = *(const uint4*)(d_o + row * DH + c * 8);
-        float fa[8], fg[8]; unpack8(a, fa); unpack8(g, fg);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += fa[j] * fg[j];
-    }
-#pragma unroll
-    for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
-    if (row < rows && c == 0) {
-        const long bt = row / H; const int head = (int)(row - bt * H);
-        const long bi = bt / T; const int t = (int)(bt - bi * T);
-        delta[(bi * H + head) * T + t] = s;
-    }
-}
-
 // ------------------------------------------------------------------------------ dK / dV (key-stationary)
 template <int DH>
 __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_kv_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ d_o,
@@ -356,7 +332,8 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_kv_kernel(cons
 // ------------------------------------------------------------------------------ dQ (query-stationary)
 template <int DH>
 __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_q_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ d_o,
-                                                         const float* __restrict__ lse, const float* __restrict__ delta,
+                                                         const unsigned short* __restrict__ o_fwd,
+                                                         const float* __restrict__ lse, float* __restrict__ delta,
                                                          unsigned short* __restrict__ dqkv, int T, int H, float scale) {
     constexpr int KK = DH / 16, DI = DH / 32, TB = tile_bytes<DH>();
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TB];
@@ -373,14 +350,22 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_q_kernel(const
     const unsigned short* vbase = base + 2L * H * DH;
     const float c_log2 = scale * 1.4426950408889634f;
 
+    // delta_q = rowsum(dO * O) of this lane's query, formed here from the dO fragments the kernel loads anyway plus the
+    // matching O fragments (a lane holds half of the row: one cross-half shuffle), and WRITTEN for the key-stationary
+    // kernel, which is launched after this one: no separate delta kernel (8.7 us + a launch, 12 x per GPT-2 step)
     bf16x8 qf[KK], dof[KK];
+    float del_q = 0.f;
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
         qf[kk] = *(const bf16x8*)(base + (long)qc * rs + 16 * kk + 8 * h);
         dof[kk] = *(const bf16x8*)(d_o + ((long)(b * T + qc) * H + head) * DH + 16 * kk + 8 * h);
+        const bf16x8 of = *(const bf16x8*)(o_fwd + ((long)(b * T + qc) * H + head) * DH + 16 * kk + 8 * h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) del_q += (float)dof[kk][j] * (float)of[j];
     }
+    del_q += __shfl_xor(del_q, 32, 64);
+    if (h == 0 && q < T) delta[((long)b * H + head) * T + q] = del_q;
     const float lse_q = lse[((long)b * H + head) * T + qc] * 1.4426950408889634f;
-    const float del_q = delta[((long)b * H + head) * T + qc];
     floatx16 dQt[DI];
 #pragma unroll
     for (int di = 0; di < DI; ++di) zero16(dQt[di]);
@@ -454,14 +439,11 @@ void launch_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, hip
 template <int DH>
 void launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,
                 int B, int T, int H, hipStream_t st) {
-    const long rows = (long)B * T * H;
-    constexpr int RPB = 256 / (DH / 8);
     const float scale = 1.0f / sqrtf((float)DH);
-    hipLaunchKernelGGL(attn_delta_kernel<DH>, dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, st, (const unsigned short*)out,
-                       (const unsigned short*)dout, delta, T, H, rows);
-    hipLaunchKernelGGL(attn_bwd_kv_kernel<DH>, dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
-                       (const unsigned short*)dout, lse, delta, (unsigned short*)dqkv, T, H, scale);
+    // query-stationary kernel first: it also produces delta = rowsum(dO * O) for the key-stationary kernel behind it
     hipLaunchKernelGGL(attn_bwd_q_kernel<DH>, dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
+                       (const unsigned short*)dout, (const unsigned short*)out, lse, delta, (unsigned short*)dqkv, T, H, scale);
+    hipLaunchKernelGGL(attn_bwd_kv_kernel<DH>, dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
                        (const unsigned short*)dout, lse, delta, (unsigned short*)dqkv, T, H, scale);
 }
 

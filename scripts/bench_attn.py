@@ -36,5 +36,5 @@ out, lse = C.attention_fwd(qkv)
 mm = 2.0 * B * H * T * T * 64 * 0.5          # one causal T x T x 64 product
 t_f = timeit(lambda: C.attention_fwd(qkv))
 t_b = timeit(lambda: C.attention_bwd(qkv, out, dout, lse))
-print(f"attention B={B} T={T} H={H} D=64   fwd {t_f:7.1f} us {2 * mm / t_f / 1e6:6.0f} TF | bwd (delta + dK/dV + dQ) {t_b:7.1f} us "
+print(f"attention B={B} T={T} H={H} D=64   fwd {t_f:7.1f} us {2 * mm / t_f / 1e6:6.0f} TF | bwd (dQ with delta + dK/dV) {t_b:7.1f} us "
       f"{7 * mm / t_b / 1e6:6.0f} TF (4 + 3 products)")
