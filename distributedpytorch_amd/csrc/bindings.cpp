@@ -706,6 +706,28 @@ Tensor softmax_ce_bwd(const Tensor& logits, const Tensor& targets, const Tensor&
     return d;
 }
 
+// One-pass cross-entropy: returns the loss [1]; `logits` (bf16 [B, ld]) is OVERWRITTEN by d loss / d logits for an
+// upstream gradient of 1.  softmax_ce_fused_ok() says whether the shape / mode allows it.
+bool softmax_ce_fused_ok(const Tensor& logits, int64_t V) {
+    return logits.is_cuda() && logits.is_contiguous() && logits.dim() == 2 &&
+           dpa::softmax_ce_fused_supported(logits.scalar_type() == at::kBFloat16, (int)V, logits.size(1), logits.data_ptr());
+}
+Tensor softmax_ce_fused(Tensor& logits, const Tensor& targets, int64_t V, double scale, int64_t ignore_index) {
+    CHECK_I64(targets);
+    TORCH_CHECK(softmax_ce_fused_ok(logits, V) && V <= logits.size(1) && targets.numel() == logits.size(0), "softmax_ce_fused: shapes");
+    Guard g(logits);
+    Tensor loss = torch::zeros({1}, logits.options().dtype(at::kFloat));
+    dpa::softmax_ce_fused(logits.data_ptr(), targets.data_ptr<int64_t>(), loss.data_ptr<float>(), logits.size(0), (int)V,
+                          logits.size(1), (float)scale, ignore_index, cur_stream());
+    return loss;
+}
+void scale_unless_one(Tensor& d, const Tensor& gscale) {
+    CHECK_BF16(d); CHECK_F32(gscale);
+    TORCH_CHECK(gscale.numel() == 1 && d.numel() % 8 == 0, "scale_unless_one: shapes");
+    Guard g(d);
+    dpa::scale_unless_one(d.data_ptr(), gscale.data_ptr<float>(), d.numel(), cur_stream());
+}
+
 // ---------------------------------------------------------------- optimizer / casts
 void sgd_momentum(Tensor& p, Tensor& grad, const c10::optional<Tensor>& m, const c10::optional<Tensor>& p_lp, double lr,
                   double mu, double wd, double grad_scale, bool zero_grad, bool nesterov,
@@ -998,6 +1020,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("ew2", &ew2);
     m.def("softmax_ce_fwd", &softmax_ce_fwd);
     m.def("softmax_ce_bwd", &softmax_ce_bwd);
+    m.def("softmax_ce_fused_ok", &softmax_ce_fused_ok);
+    m.def("softmax_ce_fused", &softmax_ce_fused);
+    m.def("scale_unless_one", &scale_unless_one);
     m.def("sgd_momentum", &sgd_momentum, py::arg("p"), py::arg("grad"), py::arg("m"), py::arg("p_lp"), py::arg("lr"), py::arg("mu"),
           py::arg("wd"), py::arg("grad_scale"), py::arg("zero_grad"), py::arg("nesterov"), py::arg("seg_ends"), py::arg("seg_wd"),
           py::arg("scale_dev") = py::none());

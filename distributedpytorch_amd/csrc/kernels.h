@@ -162,6 +162,12 @@ void softmax_ce_fwd(const void* logits, int is_bf16, const int64_t* targets, flo
 // dlogits = (softmax - onehot) * (*gscale_ptr) * scale ; may alias logits
 void softmax_ce_bwd(const void* logits, int is_bf16, const int64_t* targets, const float* lse, const float* gscale_ptr,
                     void* dlogits, long B, int V, long ld, float scale, int64_t ignore_index, hipStream_t st);
+// one-pass form (loss.hip): the bf16 logits are overwritten by their gradient for an upstream gradient of 1;
+// scale_unless_one() multiplies by the real upstream gradient when it is not 1 (device-side test, no host sync)
+bool softmax_ce_fused_supported(int is_bf16, int V, long ld, const void* logits);
+void softmax_ce_fused(void* logits, const int64_t* targets, float* loss_sum, long B, int V, long ld, float scale,
+                      int64_t ignore_index, hipStream_t st);
+void scale_unless_one(void* d_bf16, const float* g, long n, hipStream_t st);
 
 // ---------------------------------------------------------------- optimizer
 // fused SGD-momentum over a flat buffer:

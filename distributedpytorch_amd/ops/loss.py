@@ -9,7 +9,30 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
+import os
+
 from . import _ext
+
+_FUSED = os.environ.get("DPA_NO_FUSED_CE", "0") != "1"
+
+
+class _SoftmaxCEFusedFn(torch.autograd.Function):
+    """One pass: the forward kernel also overwrites the logits with their gradient (for an upstream gradient of 1);
+    backward multiplies by the real upstream gradient only when it is not 1 (tested on the device)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, n_classes, ignore_index):
+        C = _ext.load()
+        scale = 1.0 / max(logits.shape[0], 1)
+        loss = C.softmax_ce_fused(logits, targets, n_classes, scale, ignore_index)
+        ctx.save_for_backward(logits)            # now d loss / d logits
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        _ext.load().scale_unless_one(d, g.reshape(1).float().contiguous())
+        return d, None, None, None
 
 
 class _SoftmaxCEFn(torch.autograd.Function):
@@ -40,14 +63,22 @@ def softmax_cross_entropy(logits: torch.Tensor, targets: torch.Tensor, n_classes
     are classes; the rest is padding) against ``targets [B]``.  Returns an fp32 scalar.
 
     The mean is over ALL rows (like the reference's ``F.nll_loss`` on a full batch);
-    rows whose target equals ``ignore_index`` contribute zero.  ``inplace_backward`` lets
-    the backward overwrite ``logits`` with their gradient (they must not be read again).
+    rows whose target equals ``ignore_index`` contribute zero.  ``inplace_backward`` hands the
+    ``logits`` buffer over: it is overwritten with the gradient - by the backward kernel, or, when a
+    gradient is going to be asked for (bf16, row length a multiple of 8 and <= 65,536), already by the ONE forward
+    kernel that then does both passes' work - so the logits must not be read after this call.
     """
     if logits.dim() != 2:
         logits = logits.reshape(-1, logits.shape[-1])
         targets = targets.reshape(-1)
     n_classes = logits.shape[1] if n_classes is None else n_classes
     if _ext.use_hip(logits):
+        logits = logits.contiguous()
+        if (inplace_backward and _FUSED and torch.is_grad_enabled() and logits.requires_grad
+                and _ext.load().softmax_ce_fused_ok(logits, n_classes)):
+            # the logits are dead after the loss AND a gradient will be asked for: one kernel reads them once and leaves
+            # their gradient in their place (csrc/loss.hip ce_fused_kernel)
+            return _SoftmaxCEFusedFn.apply(logits, targets.contiguous(), n_classes, ignore_index)
         return _SoftmaxCEFn.apply(logits.contiguous(), targets.contiguous(), n_classes, ignore_index, inplace_backward)
     lg = logits[:, :n_classes].float()
     per_row = F.cross_entropy(lg, targets, reduction="none", ignore_index=ignore_index)

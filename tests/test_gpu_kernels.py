@@ -268,6 +268,39 @@ def test_softmax_ce(B, V, ld, dtype):
         assert float(lg.grad[:, V:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,V,ld", [(33, 50257, 50304), (64, 1000, 1000), (9, 8, 8), (17, 13, 32), (5, 65536, 65536), (20, 8193, 8208)])
+@pytest.mark.parametrize("upstream", [1.0, 2.5])
+def test_one_pass_cross_entropy_overwrites_logits_with_their_gradient(B, V, ld, upstream):
+    """``softmax_cross_entropy(..., inplace_backward=True)`` on bf16 logits that need a gradient: ONE kernel computes the
+    loss and leaves (softmax - onehot) / B where the logits were (csrc/loss.hip ``ce_fused_kernel``: the row held in
+    registers, 1..8 chunks per thread); backward multiplies by the upstream gradient only when it is not 1.  Against torch
+    fp32, with ignored rows and padded columns."""
+    from distributedpytorch_amd import ops
+    torch.manual_seed(B + V)
+    logits = (torch.randn(B, ld, device=DEV) * 3).to(torch.bfloat16)
+    t = torch.randint(0, V, (B,), device=DEV)
+    t[B // 2] = -100                                         # an ignored row
+    assert _C().softmax_ce_fused_ok(logits, V)
+    h = logits.clone().requires_grad_()
+    lg = h * 1.0                                             # a non-leaf, as the LM head's output is
+    loss = ops.softmax_cross_entropy(lg, t, V, inplace_backward=True)
+    (loss * upstream).backward()
+    lr = logits.float().cpu()[:, :V].requires_grad_()
+    ref = F.cross_entropy(lr, t.cpu(), reduction="sum", ignore_index=-100) / B
+    (ref * upstream).backward()
+    _close(loss, ref, 1e-3, 1e-3, "one-pass ce loss")
+    _close(h.grad[:, :V], lr.grad, 2e-2, 1e-5 * upstream, "one-pass ce grad")
+    assert float(h.grad[B // 2].abs().max()) == 0.0
+    if ld > V:
+        assert float(h.grad[:, V:].abs().max()) == 0.0
+    # and no gradient wanted (evaluation): the logits are left alone
+    keep = logits.clone()
+    with torch.no_grad():
+        l2 = ops.softmax_cross_entropy(keep, t, V, inplace_backward=True)
+    assert torch.equal(keep, logits)
+    _close(l2, ref, 1e-3, 1e-3, "ce loss without grad")
+
+
 def test_fused_sgd_matches_torch():
     n = 100003
     p = torch.randn(n, device=DEV); g = torch.randn(n, device=DEV); m = torch.randn(n, device=DEV)
