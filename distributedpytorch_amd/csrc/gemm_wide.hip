@@ -521,10 +521,14 @@ bool wide_gemm_eligible(const ConvArgs& a) {
     if (min_tiles == 1) return true;
     if (nk < 12) return false;
     if (s > 1 && nk < 96) return false;
-    // (Tried: forward launches - no weight-gradient kernel beside them - with one round of 256-wide tiles, where the
-    // stand-alone table says 46.9 vs 57.6 us for fc 768 -> 3072.  In the GPT-2 step: 621k vs 662k tok/s.  Stand-alone
-    // timings re-read operands that sit in the Infinity Cache; in the step they come from HBM behind the previous kernel
-    // and a 1-workgroup-per-CU persistent kernel has nothing else resident to hide that.)
+    // Mid-size launches (GPT-2's qkv / fc: 288-384 tiles) stay on the 128 x 128 kernel although scripts/bench_gemm.py
+    // shows the wide kernel ahead there (46.9 vs 57.6 us for fc 768 -> 3072): that script times launches BACK TO BACK,
+    // and with one 128-KiB workgroup per CU a launch of 1.5 items per workgroup leaves half the CUs idle during its
+    // second round - idle time the NEXT launch of the loop fills.  Inside a step the next kernel depends on this one:
+    // the kernel trace shows 82-89 us per qkv / fc launch (two full tile times) against 46 / 57 us on the 128 x 128
+    // kernel, 621k vs 662k tok/s.  DPA_WIDE_FWD=1 re-creates the experiment.
+    static const bool fwd_wide = [] { const char* e = getenv("DPA_WIDE_FWD"); return e && atoi(e) != 0; }();   // experiment switch
+    if (fwd_wide && a.mode == 0 && s == 1 && tiles >= 192) return true;
     // enough work for several items per workgroup, counted in tile-K-steps so that the answer does not depend on the
     // split factor the cost model happens to pick (the LM head's input gradient is 96 tiles x 786 K-steps: at split 5
     // it is 480 items and fell back to the 128 x 128 kernel at 1000 us instead of 554 us)
