@@ -1,0 +1,25 @@
+#!/bin/bash
+# Multi-rank flows rehearsed on ONE GPU: every rank on GPU 0 over gloo (RCCL refuses two ranks on one device), plus the
+# RCCL call path at world size 1.  The numbers printed are NOT benchmark results.   scripts/rehearse_multirank.sh
+set -o pipefail
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+mkdir -p gpurun_out/rehearse
+run() {  # name nproc args...
+    local name=$1 n=$2; shift 2
+    DPA_SHARE_GPU=1 timeout -k 10 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 \
+        --master-port $((29500 + RANDOM % 400)) bench.py --gpus $n --backend gloo "$@" > gpurun_out/rehearse/$name.log 2>&1
+    local rc=$?
+    echo "$name rc=$rc $(grep '^{' gpurun_out/rehearse/$name.log | tail -1 | cut -c1-150)"
+    [ $rc -eq 0 ] || { tail -15 gpurun_out/rehearse/$name.log; exit $rc; }
+}
+run dp2_r50 2 --batch 32 --steps 4 --warmup 2
+run dp2_gpt2 2 --model gpt2 --batch 2 --steps 4 --warmup 2
+run dp2_mnist 2 --model mnist --steps 50 --warmup 10
+run dp2_r50_sharded 2 --batch 32 --steps 4 --warmup 2 --shard-optimizer
+run pp2_mnist 2 --model mnist --pipeline 2 --steps 20 --warmup 5
+run pp4_r152 4 --model resnet152 --pipeline 4 --batch 32 --steps 3 --warmup 1
+# the RCCL path (native communicator, every bucket all-reduced for real) at world size 1
+DPA_FORCE_COLLECTIVES=1 timeout -k 10 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 \
+    --master-port $((29500 + RANDOM % 400)) bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/rehearse/rccl1_r50.log 2>&1 || { tail -15 gpurun_out/rehearse/rccl1_r50.log; exit 1; }
+echo "rccl1_r50 $(grep '^{' gpurun_out/rehearse/rccl1_r50.log | tail -1 | cut -c1-150)"
+grep -o '"comm_layer": "[^"]*"' gpurun_out/rehearse/rccl1_r50.log | tail -1
