@@ -58,6 +58,7 @@ class TrainConfig:
     # ---- model / data ----
     model: str = "mnist_cnn"
     dataset_size: int = 60000
+    dropout: float = 0.0           # GPT-2: embd / attn / resid dropout probability (the MNIST nets keep the reference's 0.5)
     # ---- engine ----
     bucket_mb: float = 32.0
     first_bucket_mb: float = 4.0
@@ -114,6 +115,7 @@ def _common_flags(p: argparse.ArgumentParser) -> None:
     p.add_argument("--momentum", default=None, type=float)
     p.add_argument("--weight-decay", default=0.0, type=float)
     p.add_argument("--seed", default=1234, type=int)
+    p.add_argument("--dropout", default=0.0, type=float, help="GPT-2 models: embedding / attention / residual dropout probability")
     p.add_argument("--model", default=None, type=str)
     p.add_argument("--dataset-size", default=60000, type=int)
     p.add_argument("--steps-per-epoch", default=None, type=int)
@@ -180,7 +182,7 @@ def config_from_args(args: argparse.Namespace, mode: str) -> TrainConfig:
         batch_size=args.batch_size,
         lr=args.lr if args.lr is not None else defaults["lr"],
         momentum=args.momentum if args.momentum is not None else defaults["momentum"],
-        weight_decay=args.weight_decay, seed=args.seed, workers=args.workers,
+        weight_decay=args.weight_decay, seed=args.seed, workers=args.workers, dropout=args.dropout,
         model=args.model or defaults["model"], dataset_size=args.dataset_size,
         steps_per_epoch=args.steps_per_epoch, device=args.device,
         checkpoint=args.checkpoint, resume=args.resume, log_json=args.log_json,

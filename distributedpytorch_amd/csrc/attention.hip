@@ -99,6 +99,15 @@ __device__ __forceinline__ bf16x8 pack_regs(const floatx16& x, int s) {   // reg
 // and overflow range handling (5 extra VALU instructions per element) buys nothing; very negative -> 0.
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Attention dropout (GPT-2's attn_pdrop): element (b, head, q, k) of the probability matrix is kept or dropped by the
+// counter hash of common.h at index ((b * H + head) * T + q) * T + k of the stream (seed, offset) - the same pure
+// function in the forward kernel and in both backward kernels, so no mask is stored (elementwise.hip's dropout_mask
+// with n = B * H * T * T reproduces the [B, H, T, T] mask for tests).  p = 0: every use is behind a wave-uniform branch.
+struct AttnDrop { float p; uint64_t seed, offset; };
+__device__ __forceinline__ float attn_keep(const AttnDrop& d, uint64_t row_base, int k, float keep_scale) {
+    return dropout_keep(d.seed, d.offset, row_base + (uint64_t)k, d.p, keep_scale);
+}
+
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 __device__ __forceinline__ void zero16(floatx16& a) {
@@ -122,9 +131,9 @@ __device__ __forceinline__ void store_T(unsigned short* __restrict__ dst, const 
 }
 
 // ------------------------------------------------------------------------------ forward
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_fwd_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
-                                                       float* __restrict__ lse, int T, int H, float c_log2) {
+                                                       float* __restrict__ lse, int T, int H, float c_log2, AttnDrop drop) {
     constexpr int KK = DH / 16, DI = DH / 32, TB = tile_bytes<DH>();
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TB];
     unsigned char* Ks = smem;
@@ -207,6 +216,14 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_fwd_kernel(const u
         rsum += __shfl_xor(rsum, 32, 64);
         l = l * alpha + rsum;
         m = mn;
+        if (DROP) {                                    // the normaliser l sees the undropped probabilities
+            const float ks = 1.f / (1.f - drop.p);
+            const uint64_t rb = ((uint64_t)(b * H + head) * T + qc) * T;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[t2][r] *= attn_keep(drop, rb, j * TILE + 32 * t2 + acc_row(r, h), ks);
+        }
 #pragma unroll
         for (int di = 0; di < DI; ++di)
 #pragma unroll
@@ -230,10 +247,10 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_fwd_kernel(const u
 }
 
 // ------------------------------------------------------------------------------ dK / dV (key-stationary)
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_kv_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ d_o,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          unsigned short* __restrict__ dqkv, int T, int H, float scale) {
+                                                          unsigned short* __restrict__ dqkv, int T, int H, float scale, AttnDrop drop) {
     constexpr int KK = DH / 16, DI = DH / 32, TB = tile_bytes<DH>();
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TB + 2 * TILE * 4];
     unsigned char* Qs = smem;
@@ -293,7 +310,17 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_kv_kernel(cons
                 dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(Os, 32 * t2 + kl, kk, h), vf[kk], dP, 0, 0, 0);
             }
             // rows = queries (registers), column = this lane's key
-            if (qt0 < kw0 + 31) {                                 // diagonal half tile: causal mask
+            if (DROP) {              // dropped probabilities: dV sees p * keep, dS = p * (keep * dP - delta)
+                const float ks = 1.f / (1.f - drop.p);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qr = 32 * t2 + acc_row(r, h), qg = min(jq * TILE + qr, T - 1);
+                    const float kp = attn_keep(drop, ((uint64_t)(b * H + head) * T + qg) * T, keyc, ks);
+                    const float p = (jq * TILE + qr >= key) ? fast_exp2(S[r] * c_log2 - lse_s[qr]) : 0.f;
+                    S[r] = p * kp;
+                    dP[r] = p * (dP[r] * kp - del_s[qr]) * scale;
+                }
+            } else if (qt0 < kw0 + 31) {                                 // diagonal half tile: causal mask
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int qr = 32 * t2 + acc_row(r, h);
@@ -330,11 +357,11 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_kv_kernel(cons
 }
 
 // ------------------------------------------------------------------------------ dQ (query-stationary)
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_q_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ d_o,
                                                          const unsigned short* __restrict__ o_fwd,
                                                          const float* __restrict__ lse, float* __restrict__ delta,
-                                                         unsigned short* __restrict__ dqkv, int T, int H, float scale) {
+                                                         unsigned short* __restrict__ dqkv, int T, int H, float scale, AttnDrop drop) {
     constexpr int KK = DH / 16, DI = DH / 32, TB = tile_bytes<DH>();
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TB];
     unsigned char* Ks = smem;
@@ -396,7 +423,16 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_q_kernel(const
                 St = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(Ks, 32 * t2 + ql, kk, h), qf[kk], St, 0, 0, 0);
                 dPt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(Vs, 32 * t2 + ql, kk, h), dof[kk], dPt, 0, 0, 0);
             }
-            if (kt0 + 31 > qw0) {                                 // diagonal half tile: causal mask
+            if (DROP) {
+                const float ks = 1.f / (1.f - drop.p);
+                const uint64_t rb = ((uint64_t)(b * H + head) * T + qc) * T;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kg = kt0 + acc_row(r, h);
+                    const float p = (kg <= qc) ? fast_exp2(St[r] * c_log2 - lse_q) : 0.f;
+                    dPt[r] = p * (dPt[r] * attn_keep(drop, rb, min(kg, T - 1), ks) - del_q) * scale;
+                }
+            } else if (kt0 + 31 > qw0) {                          // diagonal half tile: causal mask
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kg = kt0 + acc_row(r, h);
@@ -430,34 +466,44 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_q_kernel(const
 // block index equally often, heaviest blocks are dispatched first, and - 8 | H * B permitting - the blocks of one
 // (batch, head) land on one XCD, whose L2 then holds that head's K and V once.
 template <int DH>
-void launch_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, hipStream_t st) {
+void launch_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, AttnDrop drop, hipStream_t st) {
     const float c_log2 = (1.0f / sqrtf((float)DH)) * 1.4426950408889634f;   // 1/sqrt(DH) * log2(e)
-    hipLaunchKernelGGL(attn_fwd_kernel<DH>, dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
-                       (unsigned short*)out, lse, T, H, c_log2);
+    if (drop.p > 0.f)
+        hipLaunchKernelGGL((attn_fwd_kernel<DH, true>), dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
+                           (unsigned short*)out, lse, T, H, c_log2, drop);
+    else
+        hipLaunchKernelGGL((attn_fwd_kernel<DH, false>), dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
+                           (unsigned short*)out, lse, T, H, c_log2, drop);
 }
 
 template <int DH>
 void launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,
-                int B, int T, int H, hipStream_t st) {
+                int B, int T, int H, AttnDrop drop, hipStream_t st) {
     const float scale = 1.0f / sqrtf((float)DH);
     // query-stationary kernel first: it also produces delta = rowsum(dO * O) for the key-stationary kernel behind it
-    hipLaunchKernelGGL(attn_bwd_q_kernel<DH>, dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
-                       (const unsigned short*)dout, (const unsigned short*)out, lse, delta, (unsigned short*)dqkv, T, H, scale);
-    hipLaunchKernelGGL(attn_bwd_kv_kernel<DH>, dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
-                       (const unsigned short*)dout, lse, delta, (unsigned short*)dqkv, T, H, scale);
+#define DPA_ATTN_BWD(DROP_)                                                                                                          \
+    hipLaunchKernelGGL((attn_bwd_q_kernel<DH, DROP_>), dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,    \
+                       (const unsigned short*)dout, (const unsigned short*)out, lse, delta, (unsigned short*)dqkv, T, H, scale, drop); \
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<DH, DROP_>), dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,   \
+                       (const unsigned short*)dout, lse, delta, (unsigned short*)dqkv, T, H, scale, drop)
+    if (drop.p > 0.f) { DPA_ATTN_BWD(true); } else { DPA_ATTN_BWD(false); }
+#undef DPA_ATTN_BWD
 }
 
 }  // namespace
 
-void attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int Dh, hipStream_t st) {
-    if (Dh == 128) launch_fwd<128>(qkv, out, lse, B, T, H, st);
-    else launch_fwd<64>(qkv, out, lse, B, T, H, st);
+void attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int Dh, float drop_p, uint64_t seed,
+                   uint64_t offset, hipStream_t st) {
+    const AttnDrop drop{drop_p, seed, offset};
+    if (Dh == 128) launch_fwd<128>(qkv, out, lse, B, T, H, drop, st);
+    else launch_fwd<64>(qkv, out, lse, B, T, H, drop, st);
 }
 
 void attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,
-                   int B, int T, int H, int Dh, hipStream_t st) {
-    if (Dh == 128) launch_bwd<128>(qkv, out, dout, lse, dqkv, delta, B, T, H, st);
-    else launch_bwd<64>(qkv, out, dout, lse, dqkv, delta, B, T, H, st);
+                   int B, int T, int H, int Dh, float drop_p, uint64_t seed, uint64_t offset, hipStream_t st) {
+    const AttnDrop drop{drop_p, seed, offset};
+    if (Dh == 128) launch_bwd<128>(qkv, out, dout, lse, dqkv, delta, B, T, H, drop, st);
+    else launch_bwd<64>(qkv, out, dout, lse, dqkv, delta, B, T, H, drop, st);
 }
 
 }  // namespace dpa

@@ -101,9 +101,25 @@ void embedding_bwd(const Tensor& tok, const Tensor& dy, Tensor& dwte, Tensor& dw
     dpa::embedding_bwd(tok.data_ptr<int64_t>(), dy.data_ptr(), dwte.data_ptr<float>(), dwpe.data_ptr<float>(), B, T, C, dwte.size(0), cur_stream());
 }
 
+// y = (addend +) x * keep / (1 - p), the mask drawn in line from the counter hash of (seed, offset, element index)
+Tensor dropout_bf16(const Tensor& x, double p, int64_t seed, int64_t offset, const c10::optional<Tensor>& addend) {
+    CHECK_BF16(x);
+    TORCH_CHECK(p >= 0.0 && p < 1.0 && x.numel() % 8 == 0, "dropout_bf16: p in [0, 1), numel % 8 == 0");
+    const void* ad = nullptr;
+    if (addend.has_value() && addend->defined()) {
+        CHECK_BF16((*addend));
+        TORCH_CHECK(addend->numel() == x.numel(), "dropout_bf16: addend shape");
+        ad = addend->data_ptr();
+    }
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    Tensor y = torch::empty_like(x);
+    dpa::dropout_bf16(x.data_ptr(), ad, y.data_ptr(), x.numel(), (float)p, (uint64_t)seed, (uint64_t)offset, cur_stream());
+    return y;
+}
+
 #ifdef DPA_HAVE_ATTENTION
 // qkv [B,T,3,H,D] bf16 -> (out [B,T,H,D] bf16, lse [B,H,T] fp32)
-std::vector<Tensor> attention_fwd(const Tensor& qkv) {
+std::vector<Tensor> attention_fwd(const Tensor& qkv, double drop_p, int64_t seed, int64_t offset) {
     CHECK_BF16(qkv);
     TORCH_CHECK(qkv.dim() == 5 && qkv.size(2) == 3 && (qkv.size(4) == 64 || qkv.size(4) == 128), "attention: qkv must be [B,T,3,H,64|128]");
     const int64_t B = qkv.size(0), T = qkv.size(1), H = qkv.size(3), D = qkv.size(4);
@@ -111,11 +127,12 @@ std::vector<Tensor> attention_fwd(const Tensor& qkv) {
     c10::hip::HIPGuardMasqueradingAsCUDA guard(qkv.device());
     Tensor out = torch::empty({B, T, H, D}, qkv.options());
     Tensor lse = torch::empty({B, H, T}, qkv.options().dtype(at::kFloat));
-    dpa::attention_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr<float>(), B, T, H, D, cur_stream());
+    TORCH_CHECK(drop_p >= 0.0 && drop_p < 1.0, "attention: dropout probability");
+    dpa::attention_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr<float>(), B, T, H, D, (float)drop_p, (uint64_t)seed, (uint64_t)offset, cur_stream());
     return {out, lse};
 }
 
-Tensor attention_bwd(const Tensor& qkv, const Tensor& out, const Tensor& dout, const Tensor& lse) {
+Tensor attention_bwd(const Tensor& qkv, const Tensor& out, const Tensor& dout, const Tensor& lse, double drop_p, int64_t seed, int64_t offset) {
     CHECK_BF16(qkv); CHECK_BF16(out); CHECK_BF16(dout); CHECK_F32(lse);
     TORCH_CHECK(qkv.dim() == 5 && qkv.size(2) == 3 && (qkv.size(4) == 64 || qkv.size(4) == 128), "attention_bwd: qkv must be [B,T,3,H,64|128]");
     const int64_t B = qkv.size(0), T = qkv.size(1), H = qkv.size(3), D = qkv.size(4);
@@ -124,7 +141,7 @@ Tensor attention_bwd(const Tensor& qkv, const Tensor& out, const Tensor& dout, c
     Tensor dqkv = torch::empty_like(qkv);
     Tensor delta = torch::empty({B, H, T}, lse.options());
     dpa::attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr<float>(), dqkv.data_ptr(),
-                       delta.data_ptr<float>(), B, T, H, D, cur_stream());
+                       delta.data_ptr<float>(), B, T, H, D, (float)drop_p, (uint64_t)seed, (uint64_t)offset, cur_stream());
     return dqkv;
 }
 #endif
@@ -138,8 +155,12 @@ void bind_transformer(pybind11::module_& m) {
     m.def("ln_fold_partials", &ln_fold_partials);
     m.def("embedding_fwd", &embedding_fwd);
     m.def("embedding_bwd", &embedding_bwd);
+    m.def("dropout_bf16", &dropout_bf16, pybind11::arg("x"), pybind11::arg("p"), pybind11::arg("seed"), pybind11::arg("offset"),
+          pybind11::arg("addend") = pybind11::none());
 #ifdef DPA_HAVE_ATTENTION
-    m.def("attention_fwd", &attention_fwd);
-    m.def("attention_bwd", &attention_bwd);
+    m.def("attention_fwd", &attention_fwd, pybind11::arg("qkv"), pybind11::arg("drop_p") = 0.0, pybind11::arg("seed") = 0,
+          pybind11::arg("offset") = 0);
+    m.def("attention_bwd", &attention_bwd, pybind11::arg("qkv"), pybind11::arg("out"), pybind11::arg("dout"), pybind11::arg("lse"),
+          pybind11::arg("drop_p") = 0.0, pybind11::arg("seed") = 0, pybind11::arg("offset") = 0);
 #endif
 }

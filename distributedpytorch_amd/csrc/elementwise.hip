@@ -297,6 +297,24 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ m
     GRID_STRIDE(i, n) mask[i] = dropout_keep(seed, offset, (uint64_t)i, p, keep_scale);
 }
 
+// element dropout of a bf16 tensor with the mask drawn in line (no mask tensor), optionally added to a residual
+__global__ __launch_bounds__(256) void dropout_bf16_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ addend,
+                                                           unsigned short* __restrict__ y, long nchunks, float p, uint64_t seed,
+                                                           uint64_t offset) {
+    const float keep_scale = 1.f / (1.f - p);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long)gridDim.x * 256) {
+        float f[8]; unpack8(*(const uint4*)(x + i * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] *= dropout_keep(seed, offset, (uint64_t)(i * 8 + j), p, keep_scale);
+        if (addend != nullptr) {
+            float a[8]; unpack8(*(const uint4*)(addend + i * 8), a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += a[j];
+        }
+        *(uint4*)(y + i * 8) = pack8(f);
+    }
+}
+
 }  // namespace
 
 void maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int Ho, int Wo, hipStream_t st) {
@@ -416,5 +434,11 @@ void reduce_shards_bf16(float* dst, const void* src, int nsrc, long stride, long
 __global__ void counter_add_kernel(int64_t* c, int64_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += v; }
 
 void counter_add(int64_t* c, int64_t v, hipStream_t st) { hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, st, c, v); }
+
+void dropout_bf16(const void* x, const void* addend, void* y, long n, float p, uint64_t seed, uint64_t offset, hipStream_t st) {
+    const long nchunks = n / 8;
+    hipLaunchKernelGGL(dropout_bf16_kernel, dim3(grid_for(nchunks)), dim3(256), 0, st, (const unsigned short*)x,
+                       (const unsigned short*)addend, (unsigned short*)y, nchunks, p, seed, offset);
+}
 
 }  // namespace dpa

@@ -196,9 +196,15 @@ void reduce_partials2(const float* partial, int rows, int C, float* out_a, float
 void embedding_fwd(const int64_t* tok, const void* wte, const void* wpe, void* y, long B, int T, int C, long V, hipStream_t st);
 void embedding_bwd(const int64_t* tok, const void* dy, float* dwte, float* dwpe, long B, int T, int C, long V, hipStream_t st);
 // causal flash attention, qkv packed [B, T, 3, H, D] bf16, D = 64
-void attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int D, hipStream_t st);
+// drop_p > 0: attention dropout, element (b, h, q, k) kept by the counter hash at index ((b*H + h)*T + q)*T + k of the
+// stream (seed, offset) - dropout_mask() with n = B*H*T*T reproduces the mask
+void attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int D, float drop_p, uint64_t seed,
+                   uint64_t offset, hipStream_t st);
 void attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,
-                   int B, int T, int H, int D, hipStream_t st);
+                   int B, int T, int H, int D, float drop_p, uint64_t seed, uint64_t offset, hipStream_t st);
+// y = addend + x * keep(seed, offset, i) / (1 - p)  (bf16, n % 8 == 0; addend optional): element dropout with the mask
+// drawn in line, fused with the residual add that follows it in a transformer block
+void dropout_bf16(const void* x, const void* addend, void* y, long n, float p, uint64_t seed, uint64_t offset, hipStream_t st);
 
 // ---------------------------------------------------------------- small MNIST CNN (fp32, NCHW; reference model)
 // y = dropout2d(relu(maxpool2(conv5x5(x) + b))) fused ; idx = argmax position in the 2x2 window.  drop_p > 0: one keep/drop

@@ -6,7 +6,8 @@ h.N.mlp.c_proj ln_f``); ``checkpoint.py`` transposes the ``Conv1D`` weights at t
 save/load edge.  All GEMMs (QKV, proj, MLP, tied LM head) run on the implicit-GEMM
 MFMA kernel in bf16 with fp32 accumulation; attention is the causal flash kernel;
 LayerNorm / GELU / residual adds are streaming kernels; the 50,257-class softmax
-cross-entropy is fused and its backward runs in place over the logits.
+cross-entropy is fused and its backward runs in place over the logits.  Dropout (``GPT2Config.dropout``: embedding,
+attention probabilities, residual branches) is drawn inside the kernels from a counter hash - no mask tensors.
 """
 from __future__ import annotations
 
@@ -29,21 +30,49 @@ class GPT2Config:
     n_embd: int = 768
     n_layer: int = 12
     n_head: int = 12
+    dropout: float = 0.0       # embd_pdrop = attn_pdrop = resid_pdrop (HuggingFace's default is 0.1; 0.0 is the usual
+                               # pre-training / benchmark setting and what bench.py runs)
+    dropout_seed: int = 1234
 
     @property
     def vocab_padded(self) -> int:
         return (self.vocab_size + 63) // 64 * 64
 
 
+class _DropSites:
+    """Dropout streams of one module: site ``k`` of call ``n`` draws from the counter-hash stream at offset
+    ``(n * sites + k) << 36`` - disjoint index ranges (a site has far fewer than 2^36 elements), masks a pure function
+    of (seed, call, site, element), so backward re-draws them and nothing is stored.  Every module counts its own
+    calls, which keeps pipeline stages (each holding only its blocks) independent of one another."""
+
+    def __init__(self, p: float, seed: int, sites: int):
+        self.p, self.seed, self.sites, self.calls = float(p), int(seed), sites, 0
+
+    def begin(self, training: bool) -> bool:
+        """One forward call of the owning module; returns whether dropout is active."""
+        on = training and self.p > 0.0
+        if on:
+            self.calls += 1
+        return on
+
+    def site(self, k: int):
+        return (self.p, self.seed, ((self.calls * self.sites + k) << 36) & ((1 << 62) - 1))
+
+
 class Attention(nn.Module):
-    def __init__(self, cfg: GPT2Config):
+    def __init__(self, cfg: GPT2Config, layer: int = 0):
         super().__init__()
         self.n_head = cfg.n_head
         self.c_attn = Linear(cfg.n_embd, 3 * cfg.n_embd, init_std=0.02)
         self.c_proj = Linear(cfg.n_embd, cfg.n_embd, init_std=0.02 / math.sqrt(2 * cfg.n_layer))
+        self._drop = _DropSites(cfg.dropout, cfg.dropout_seed + 7919 * (2 * layer + 1), 2)
 
     def forward(self, x, residual=None):
-        return self.c_proj(ops.causal_attention(self.c_attn(x), self.n_head), residual=residual)
+        if not self._drop.begin(self.training):
+            return self.c_proj(ops.causal_attention(self.c_attn(x), self.n_head), residual=residual)
+        # attn_pdrop inside the attention kernels, resid_pdrop fused with the residual add behind the projection
+        a = ops.causal_attention(self.c_attn(x), self.n_head, drop=self._drop.site(0))
+        return ops.dropout_residual(self.c_proj(a), *self._drop.site(1), residual=residual)
 
 
 # opt-in: measured 1 % SLOWER than the elementwise GELU pass it removes (599.0k vs 604.7k tok/s, docs/DESIGN.md §6)
@@ -51,12 +80,16 @@ _GELU_TWIN = os.environ.get("DPA_GELU_TWIN", "0") == "1"
 
 
 class MLP(nn.Module):
-    def __init__(self, cfg: GPT2Config):
+    def __init__(self, cfg: GPT2Config, layer: int = 0):
         super().__init__()
         self.c_fc = Linear(cfg.n_embd, 4 * cfg.n_embd, init_std=0.02)
         self.c_proj = Linear(4 * cfg.n_embd, cfg.n_embd, init_std=0.02 / math.sqrt(2 * cfg.n_layer))
+        self._drop = _DropSites(cfg.dropout, cfg.dropout_seed + 7919 * (2 * layer + 2), 1)
 
     def forward(self, x, residual=None):
+        if self._drop.begin(self.training):
+            y = self.c_proj(self.c_fc(x), pre_gelu=True)
+            return ops.dropout_residual(y, *self._drop.site(0), residual=residual)
         # gelu inside c_proj: its backward is an epilogue of c_proj's input-gradient GEMM.  With DPA_GELU_TWIN=1 c_fc's
         # epilogue also writes gelu(h) beside h, so the forward elementwise pass disappears too
         if _GELU_TWIN:
@@ -66,12 +99,12 @@ class MLP(nn.Module):
 
 
 class Block(nn.Module):
-    def __init__(self, cfg: GPT2Config):
+    def __init__(self, cfg: GPT2Config, layer: int = 0):
         super().__init__()
         self.ln_1 = LayerNorm(cfg.n_embd)
-        self.attn = Attention(cfg)
+        self.attn = Attention(cfg, layer)
         self.ln_2 = LayerNorm(cfg.n_embd)
-        self.mlp = MLP(cfg)
+        self.mlp = MLP(cfg, layer)
 
     def forward(self, x):
         # pre-norm residual blocks: the forward add rides the projection GEMM's epilogue, the backward add of the
@@ -97,11 +130,14 @@ class Embedding(nn.Module):
         self.wte_lp_t = None               # bf16 [n_embd, vocab] twin for the tied head's input gradient (FlatParams)
         self._dpa_twins = ("wte",)
         self._dpa_tie = ("wte", "first")   # pipeline: this matrix also lives in the LM-head stage (parallel/pp.py)
+        self._drop = _DropSites(cfg.dropout, cfg.dropout_seed, 1)
 
     def forward(self, tokens):
         x = ops.embedding(tokens, self.wte, self.wpe, self.wte_lp, self.wpe_lp)
         if x.is_cuda and x.dtype != torch.bfloat16:
             x = x.to(torch.bfloat16)
+        if self._drop.begin(self.training):      # embd_pdrop
+            x = ops.dropout_residual(x, *self._drop.site(0))
         return x
 
 
@@ -110,7 +146,7 @@ class GPT2(nn.Module):
         super().__init__()
         self.cfg = cfg
         self.emb = Embedding(cfg)
-        self.h = nn.ModuleList([Block(cfg) for _ in range(cfg.n_layer)])
+        self.h = nn.ModuleList([Block(cfg, i) for i in range(cfg.n_layer)])
         self.ln_f = LayerNorm(cfg.n_embd)
 
     def hidden(self, tokens: torch.Tensor) -> torch.Tensor:
@@ -156,8 +192,10 @@ def gpt2_small() -> GPT2:
     return GPT2(GPT2Config())
 
 
-def gpt2_tiny(n_layer: int = 2, n_embd: int = 128, n_head: int = 2, vocab: int = 500, n_positions: int = 128) -> GPT2:
-    return GPT2(GPT2Config(vocab_size=vocab, n_positions=n_positions, n_embd=n_embd, n_layer=n_layer, n_head=n_head))
+def gpt2_tiny(n_layer: int = 2, n_embd: int = 128, n_head: int = 2, vocab: int = 500, n_positions: int = 128,
+              dropout: float = 0.0) -> GPT2:
+    return GPT2(GPT2Config(vocab_size=vocab, n_positions=n_positions, n_embd=n_embd, n_layer=n_layer, n_head=n_head,
+                           dropout=dropout))
 
 
 def flops_per_token(cfg: GPT2Config, seq_len: int) -> float:

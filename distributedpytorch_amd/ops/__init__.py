@@ -11,4 +11,4 @@ from .norm import batch_norm_nhwc, layer_norm, layer_norm_fork  # noqa: F401
 from .misc import (max_pool_3x3_s2_nhwc, global_avg_pool_nhwc, to_nhwc, add_relu, add, gelu)  # noqa: F401
 from .loss import softmax_cross_entropy  # noqa: F401
 from .small import (conv5_pool_relu, linear_f32, linear_log_softmax, linear_log_softmax_nll, dropout, channel_dropout_mask, log_softmax, nll_loss)  # noqa: F401
-from .tfm import embedding, causal_attention  # noqa: F401
+from .tfm import embedding, causal_attention, dropout_residual  # noqa: F401

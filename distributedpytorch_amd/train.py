@@ -37,7 +37,7 @@ def pick_device(cfg: TrainConfig, local_rank: int) -> torch.device:
     return torch.device("cpu")
 
 
-def build_model(name: str):
+def build_model(name: str, dropout: float = 0.0):
     """Returns (model, dataset_kind, loss(model, x, y), use_lp, classes)."""
     from . import ops
     if name == "mnist_cnn":
@@ -50,7 +50,7 @@ def build_model(name: str):
         return m, ("tiny_image" if name == "tiny_resnet" else "imagenet"), (lambda mod, x, y: mod.loss(x, y)), True, m.num_classes
     if name in ("gpt2", "gpt2_small", "gpt2_tiny"):
         from .models import gpt2
-        m = gpt2.gpt2_tiny() if name == "gpt2_tiny" else gpt2.gpt2_small()
+        m = gpt2.gpt2_tiny(dropout=dropout) if name == "gpt2_tiny" else gpt2.GPT2(gpt2.GPT2Config(dropout=dropout))
         return m, "tokens", (lambda mod, x, y: mod.loss(x, y)), True, m.cfg.vocab_size
     raise ValueError(f"unknown model {name!r}")
 
@@ -81,7 +81,7 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
     last = None
     try:
         torch.manual_seed(cfg.seed)                      # identical initial replicas (DP.py:138) ...
-        model, kind, loss_fn, use_lp, classes = build_model(cfg.model)
+        model, kind, loss_fn, use_lp, classes = build_model(cfg.model, cfg.dropout)
         model = model.to(device).train()
         dataset = build_dataset(kind, cfg, classes, model, device)
         loader, bsz = ddata.partition_dataset(dataset, comm.rank, comm.world_size, cfg.batch_size, cfg.seed, device,
@@ -217,7 +217,7 @@ def run_mp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
             loss_fn = mnist.nll_loss
             kind, classes, use_lp = "mnist", 10, False
         else:
-            full, kind, _, use_lp, classes = build_model(cfg.model)
+            full, kind, _, use_lp, classes = build_model(cfg.model, cfg.dropout)
             layers = full.pipeline_layers()
             # stages balanced by measured forward+backward TIME on the GPU (rank 0's measurement, so every rank cuts
             # at the same layers); by parameter count only where nothing can be timed (CPU)

@@ -623,6 +623,64 @@ def test_causal_attention_fwd_bwd(B, T, H, D):
         _close(g[:, :, i], gr[:, :, i], 3e-2, 3e-2, "attention " + name)
 
 
+@pytest.mark.parametrize("B,T,H,D", [(2, 200, 3, 64), (1, 256, 2, 64), (1, 130, 2, 128)])
+def test_causal_attention_with_dropout_matches_masked_reference(B, T, H, D):
+    """Attention dropout drawn INSIDE the three kernels (csrc/attention.hip ``AttnDrop``): the kept / dropped pattern is
+    the counter hash at index ((b*H + h)*T + q)*T + k, which ``dropout_mask`` reproduces as a [B, H, T, T] tensor for
+    the fp32 oracle ``(softmax(QK^T/sqrt(d)) * mask) V``; forward and all three gradients."""
+    from distributedpytorch_amd import ops
+    p, seed, offset = 0.25, 99, 5 << 36
+    qkv = _rand_bf16(B, T, 3 * H * D, seed=41).requires_grad_()
+    out = ops.causal_attention(qkv, H, drop=(p, seed, offset))
+    dout = _rand_bf16(B, T, H * D, seed=42)
+    out.backward(dout)
+    keep = _C().dropout_mask(B * H * T * T, p, seed, offset, qkv, None).cpu().view(B, H, T, T)
+    assert 0.65 < float((keep > 0).float().mean()) < 0.85
+    qr = qkv.detach().float().cpu().requires_grad_()
+    q, k, v = qr.view(B, T, 3, H, D).permute(2, 0, 3, 1, 4)
+    att = (q @ k.transpose(-2, -1)) / math.sqrt(D)
+    att = att.masked_fill(~torch.ones(T, T, dtype=torch.bool).tril(), float("-inf")).softmax(dim=-1) * keep
+    outr = (att @ v).permute(0, 2, 1, 3).reshape(B, T, H * D)
+    outr.backward(dout.float().cpu())
+    _close(out, outr, 2e-2, 2e-2, "attention+dropout out")
+    g, gr = qkv.grad.float().cpu().view(B, T, 3, H, D), qr.grad.view(B, T, 3, H, D)
+    for i, name in enumerate(("dq", "dk", "dv")):
+        _close(g[:, :, i], gr[:, :, i], 3e-2, 4e-2, "attention+dropout " + name)
+    # the no-dropout path is untouched by the feature
+    o0 = ops.causal_attention(qkv.detach(), H)
+    o1 = ops.causal_attention(qkv.detach(), H, drop=(0.0, seed, offset))
+    assert torch.equal(o0, o1)
+
+
+def test_dropout_residual_bf16_and_gpt2_with_dropout():
+    """``ops.dropout_residual`` (mask drawn in line, fused with the residual add) against the explicit mask, forward and
+    backward; then a tiny GPT-2 with ``dropout = 0.1``: trains (finite loss and gradients), draws fresh masks per call,
+    and is deterministic in eval mode."""
+    from distributedpytorch_amd import ops
+    from distributedpytorch_amd.models import gpt2
+    p, seed, offset = 0.1, 7, 3 << 36
+    x = _rand_bf16(6, 40, 128, seed=51).requires_grad_()
+    r = _rand_bf16(6, 40, 128, seed=52).requires_grad_()
+    y = ops.dropout_residual(x, p, seed, offset, residual=r)
+    dy = _rand_bf16(6, 40, 128, seed=53)
+    y.backward(dy)
+    keep = _C().dropout_mask(x.numel(), p, seed, offset, x, None).view(x.shape)
+    _close(y, x.detach().float() * keep + r.detach().float(), 1e-2, 1e-2, "dropout_residual")
+    _close(x.grad, dy.float() * keep, 1e-2, 1e-2, "dropout_residual dx")
+    assert torch.equal(r.grad, dy)
+    assert 0.85 < float((keep > 0).float().mean()) < 0.95
+    torch.manual_seed(0)
+    m = gpt2.gpt2_tiny(n_layer=2, n_embd=128, n_head=2, vocab=500, n_positions=128, dropout=0.1).to(DEV).train()
+    tok = torch.randint(0, 500, (2, 128), device=DEV)
+    l1 = m.loss(tok, tok); l1.backward()
+    assert torch.isfinite(l1) and all(torch.isfinite(q.grad).all() for q in m.parameters() if q.grad is not None)
+    l2 = m.loss(tok, tok)
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = m.loss(tok, tok), m.loss(tok, tok)
+    assert abs(float(e1) - float(e2)) < 1e-4 and abs(float(l1) - float(l2)) > 1e-4     # (loss rows are summed with float atomics)
+
+
 def test_bn_apply_with_affine_residual_matches_fp32_reference():
     """bn_apply(x, r, ..., res_scale, res_shift): relu(x*s + b + (r*rs + rb)) - the projection shortcut's BatchNorm folded
     into bn3's apply (ops/block.py fold_ds) - against the plain fp32 expression."""

@@ -139,6 +139,23 @@ def test_gpt2_tiny_cpu_and_hf_export(tmp_path):
     assert abs(n - 124.4e6) < 0.5e6
 
 
+def test_gpt2_dropout_on_cpu_is_active_in_training_only():
+    """``GPT2Config.dropout`` (embedding, attention probabilities, residual branches): CPU fallback of the in-kernel
+    dropout - training calls differ from one another and from eval, eval calls agree, gradients flow."""
+    torch.manual_seed(0)
+    m = gpt2.gpt2_tiny(n_layer=2, n_embd=64, n_head=2, vocab=300, n_positions=32, dropout=0.2).train()
+    tok = torch.randint(0, 300, (2, 32))
+    l1 = m.loss(tok, tok); l1.backward()
+    l2 = m.loss(tok, tok)
+    assert torch.isfinite(l1) and abs(float(l1) - float(l2)) > 1e-6
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    m.eval()
+    with torch.no_grad():
+        assert float(m.loss(tok, tok)) == float(m.loss(tok, tok))
+    m0 = gpt2.gpt2_tiny(n_layer=2, n_embd=64, n_head=2, vocab=300, n_positions=32).train()
+    assert float(m0.loss(tok, tok)) == float(m0.loss(tok, tok))          # dropout 0: no stream, no randomness
+
+
 def test_checkpoint_carries_the_dropout_stream_position(tmp_path):
     """the MNIST nets' counter-based dropout stream resumes where it stopped (the next masks, not the first)."""
     import torch
