@@ -321,27 +321,48 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const unsigned
     }
 }
 
-// gradient reaching input position (n, hi, wi), channels 8 ch .. 8 ch + 7, through the pooling windows that hold it
-__device__ __forceinline__ void pool_grad_gather(const unsigned short* __restrict__ dp, const unsigned char* __restrict__ idx,
-                                                 int n, int hi, int wi, int ch, int Ho, int Wo, int cpr, float (&g)[8]) {
+// Backward through the 3x3 / stride 2 / pad 1 max pool, by 2 x 2 PATCHES of input positions: the four positions
+// (2a + da, 2b + db) of patch (a, b) are reached through exactly the four windows (a + ea, b + eb) - position da = 0 lies in
+// window ea = 0 only (tap row 1), da = 1 in ea = 0 (tap row 2) and ea = 1 (tap row 0); columns alike.  One thread handles
+// a patch x 8 channels: 4 window loads (winning-tap bytes + pooled gradient) serve 4 positions - 24 B of gather traffic
+// per position instead of 54 when every position fetches its own 1 / 2 / 2 / 4 windows - and all of a thread's loads
+// are independent of one another (one memory round trip; the per-position form looped over a data-dependent window
+// nest and was bound by the texture path: 245 + 312 us for the two stem kernels at batch 256).
+__device__ __forceinline__ void pool_patch_gather(const unsigned short* __restrict__ dp, const unsigned char* __restrict__ idx,
+                                                  int n, int a, int b, int ch, int Ho, int Wo, int cpr, float (&g)[4][8]) {
+    uint2 ik[4];
+    uint4 dv[4];
+    bool ok[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = 0.f;
-    const int ho_lo = hi >> 1, ho_hi = (hi + 1) >> 1, wo_lo = wi >> 1, wo_hi = (wi + 1) >> 1;
-    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
-        if (ho >= Ho) continue;
-        const int r = hi - (ho * 2 - 1);
-        for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-            if (wo >= Wo) continue;
-            const unsigned tap = (unsigned)(r * 3 + (wi - (wo * 2 - 1)));
+    for (int ea = 0; ea < 2; ++ea)
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) {
+            const int w_ = ea * 2 + eb;
+            ok[w_] = (a + ea < Ho) && (b + eb < Wo);
+            const int ho = min(a + ea, Ho - 1), wo = min(b + eb, Wo - 1);      // invalid: re-read a valid window, count it as zero
             const size_t o = ((size_t)(n * Ho + ho) * Wo + wo) * cpr + ch;
-            const uint2 ik = *(const uint2*)(idx + o * 8);
-            const uint4 dv = *(const uint4*)(dp + o * 8);
-            float d[8]; unpack8(dv, d);
+            ik[w_] = *(const uint2*)(idx + o * 8);
+            dv[w_] = *(const uint4*)(dp + o * 8);
+        }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned t = ((j < 4 ? ik.x : ik.y) >> ((j & 3) * 8)) & 0xffu;
-                g[j] += t == tap ? d[j] : 0.f;
-            }
+    for (int p_ = 0; p_ < 4; ++p_)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[p_][j] = 0.f;
+#pragma unroll
+    for (int w_ = 0; w_ < 4; ++w_) {
+        const int ea = w_ >> 1, eb = w_ & 1;
+        float d[8]; unpack8(dv[w_], d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned t = ((j < 4 ? ik[w_].x : ik[w_].y) >> ((j & 3) * 8)) & 0xffu;
+            const float dj = ok[w_] ? d[j] : 0.f;
+#pragma unroll
+            for (int da = ea; da < 2; ++da)
+#pragma unroll
+                for (int db = eb; db < 2; ++db) {
+                    const unsigned r = da == 0 ? 1u : (ea == 0 ? 2u : 0u), c = db == 0 ? 1u : (eb == 0 ? 2u : 0u);
+                    g[da * 2 + db][j] += t == r * 3u + c ? dj : 0.f;
+                }
         }
     }
 }
@@ -349,22 +370,35 @@ __device__ __forceinline__ void pool_grad_gather(const unsigned short* __restric
 __global__ __launch_bounds__(256) void pool_bn_bwd_stats_kernel(const unsigned short* __restrict__ dp, const unsigned char* __restrict__ idx,
                                                                 const unsigned short* __restrict__ x, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, float* __restrict__ stats,
-                                                                long P, int C, int H, int W, int Ho, int Wo, int rpb, int replicas) {
+                                                                long patches, int C, int H, int W, int Ho, int Wo, int rpb, int replicas) {
     const int cpr = C / 8;
-    reduce_rows([&](long r, int ch, float (&s)[8], float (&q)[8]) {
-        const unsigned pix = (unsigned)r;
-        const int wi = (int)(pix % (unsigned)W); const unsigned t = pix / (unsigned)W;
-        const int hi = (int)(t % (unsigned)H), n = (int)(t / (unsigned)H);
-        float g[8], xf[8];
-        pool_grad_gather(dp, idx, n, hi, wi, ch, Ho, Wo, cpr, g);
-        const uint4 xv = *(const uint4*)(x + r * C + ch * 8);
-        unpack8(xv, xf);
+    reduce_rows([&](long r, int ch, float (&s)[8], float (&q)[8]) {          // "row" = one 2 x 2 patch
+        const unsigned pt = (unsigned)r;
+        const int b = (int)(pt % (unsigned)Wo); const unsigned t = pt / (unsigned)Wo;
+        const int a = (int)(t % (unsigned)Ho), n = (int)(t / (unsigned)Ho);
+        uint4 xv[4];
+        bool in[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xh = (xf[j] - mean[ch * 8 + j]) * invstd[ch * 8 + j];
-            s[j] += g[j]; q[j] += g[j] * xh;
+        for (int p_ = 0; p_ < 4; ++p_) {
+            const int hi = 2 * a + (p_ >> 1), wi = 2 * b + (p_ & 1);
+            in[p_] = hi < H && wi < W;
+            xv[p_] = *(const uint4*)(x + (((size_t)n * H + min(hi, H - 1)) * W + min(wi, W - 1)) * C + ch * 8);
         }
-    }, stats, P, C, rpb, replicas);
+        float g[4][8];
+        pool_patch_gather(dp, idx, n, a, b, ch, Ho, Wo, cpr, g);
+        float mu[8], is[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mu[j] = mean[ch * 8 + j]; is[j] = invstd[ch * 8 + j]; }
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) {
+            float xf[8]; unpack8(xv[p_], xf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float gj = in[p_] ? g[p_][j] : 0.f;
+                s[j] += gj; q[j] += gj * ((xf[j] - mu[j]) * is[j]);
+            }
+        }
+    }, stats, patches, C, rpb, replicas);
 }
 
 __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const unsigned short* __restrict__ dp, const unsigned char* __restrict__ idx,
@@ -373,19 +407,36 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const unsigned s
                                                                 unsigned short* __restrict__ dx, int N, int H, int W, int C,
                                                                 int Ho, int Wo) {
     const int cpr = C / 8;
-    const unsigned total = (unsigned)N * H * W * cpr;
+    const unsigned total = (unsigned)N * Ho * Wo * cpr;                       // patches x channel chunks
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
         const int ch = (int)(i % cpr);
         unsigned p = i / cpr;
-        const int wi = (int)(p % W); p /= W;
-        const int hi = (int)(p % H);
-        const int n = (int)(p / H);
-        float g[8], xf[8], o[8];
-        pool_grad_gather(dp, idx, n, hi, wi, ch, Ho, Wo, cpr, g);
-        { const uint4 v = *(const uint4*)(x + (size_t)i * 8); unpack8(v, xf); }
+        const int b = (int)(p % Wo); p /= Wo;
+        const int a = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        uint4 xv[4];
+        bool in[4];
+        size_t off[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(cA[ch * 8 + j], g[j], __builtin_fmaf(cB[ch * 8 + j], xf[j], cC[ch * 8 + j]));   // same association as tail_bwd.hip
-        *(uint4*)(dx + (size_t)i * 8) = pack8(o);
+        for (int p_ = 0; p_ < 4; ++p_) {
+            const int hi = 2 * a + (p_ >> 1), wi = 2 * b + (p_ & 1);
+            in[p_] = hi < H && wi < W;
+            off[p_] = (((size_t)n * H + min(hi, H - 1)) * W + min(wi, W - 1)) * C + ch * 8;
+            xv[p_] = *(const uint4*)(x + off[p_]);
+        }
+        float g[4][8];
+        pool_patch_gather(dp, idx, n, a, b, ch, Ho, Wo, cpr, g);
+        float ka[8], kb[8], kc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ka[j] = cA[ch * 8 + j]; kb[j] = cB[ch * 8 + j]; kc[j] = cC[ch * 8 + j]; }
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) {
+            if (!in[p_]) continue;
+            float xf[8], o[8]; unpack8(xv[p_], xf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(ka[j], g[p_][j], __builtin_fmaf(kb[j], xf[j], kc[j]));   // same association as tail_bwd.hip
+            *(uint4*)(dx + off[p_]) = pack8(o);
+        }
     }
 }
 
@@ -473,14 +524,15 @@ void bn_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, 
 
 void pool_bn_bwd_stats(const void* dp, const unsigned char* idx, const void* x, const float* mean, const float* invstd,
                        float* stats, int N, int H, int W, int C, int Ho, int Wo, int replicas, hipStream_t st) {
-    const long P = (long)N * H * W;
-    hipLaunchKernelGGL(pool_bn_bwd_stats_kernel, dim3(bn_stats_rows(P)), dim3(256), 0, st, (const unsigned short*)dp, idx,
-                       (const unsigned short*)x, mean, invstd, stats, P, C, H, W, Ho, Wo, rows_per_block(P), replicas);
+    const long P = (long)N * H * W, patches = (long)N * Ho * Wo;      // grid as for a P-row reduction (the callers size the
+    const int grid = bn_stats_rows(P);                               // partial-row buffer by bn_stats_rows(P)); work = patches
+    hipLaunchKernelGGL(pool_bn_bwd_stats_kernel, dim3(grid), dim3(256), 0, st, (const unsigned short*)dp, idx,
+                       (const unsigned short*)x, mean, invstd, stats, patches, C, H, W, Ho, Wo, (int)((patches + grid - 1) / grid), replicas);
 }
 
 void pool_bn_bwd_apply(const void* dp, const unsigned char* idx, const void* x, const float* coefA, const float* coefB,
                        const float* coefC, void* dx, int N, int H, int W, int C, int Ho, int Wo, hipStream_t st) {
-    const long total = (long)N * H * W * (C / 8);
+    const long total = (long)N * Ho * Wo * (C / 8);
     hipLaunchKernelGGL(pool_bn_bwd_apply_kernel, dim3(stream_grid(total)), dim3(256), 0, st, (const unsigned short*)dp, idx,
                        (const unsigned short*)x, coefA, coefB, coefC, (unsigned short*)dx, N, H, W, C, Ho, Wo);
 }
