@@ -268,13 +268,14 @@ class RcclComm {
     }
 
     // the CURRENT stream waits for the operation behind `ticket` (no host block)
+    // A ticket may be waited for from SEVERAL streams (the optimizer's stream behind one bucket, the compute stream in
+    // DataParallel.finish()): the event stays until it has completed, finish() prunes completed ones.
     void wait(int64_t ticket) {
         auto it = pending_.find(ticket);
-        if (it == pending_.end()) return;                     // already waited for
+        if (it == pending_.end()) return;                     // completed and pruned
         c10::hip::HIPGuardMasqueradingAsCUDA guard(dev());
         Stream cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(device_);
         it->second->block(cur);
-        pending_.erase(it);
     }
 
     // host-side: is the operation behind `ticket` complete? (watchdog / tests)
@@ -321,6 +322,8 @@ class RcclComm {
     int64_t finish(const std::vector<Tensor>& used) {
         for (const Tensor& t : used)
             c10::hip::HIPCachingAllocatorMasqueradingAsCUDA::recordStreamMasqueradingAsCUDA(t.storage().data_ptr(), stream_);
+        for (auto it = pending_.begin(); it != pending_.end();)          // operations that have completed need no event any more
+            it = it->second->query() ? pending_.erase(it) : std::next(it);
         auto done = std::make_unique<at::cuda::CUDAEvent>(hipEventDisableTiming);
         done->record(stream_);
         const int64_t ticket = next_ticket_++;

@@ -36,6 +36,71 @@ class FusedSGD:
         # contiguous runs of the flat buffer sharing the same weight decay -> one launch each
         self.segments = self._segments(no_decay)
         self._seg_ends = self._seg_wd = None
+        self._ov = None                    # overlapped mode (overlap_with_backward)
+
+    # ---- optimizer overlapped with backward -------------------------------------------------------------------
+    def overlap_with_backward(self, dp, enabled: bool = True) -> bool:
+        """Update every gradient bucket's parameters as soon as its reduction has been issued - on a stream of its own,
+        ordered behind that reduction - instead of in one launch after backward.  The update is pure HBM traffic
+        (26 bytes per parameter: 0.7 ms for GPT-2's 124M) that otherwise runs alone at the end of the step; backward's
+        GEMMs leave the bandwidth for it.  Safe because nothing enqueued after a bucket's last gradient reads that
+        bucket's fp32 masters or bf16 shadows: input-gradient kernels read the TRANSPOSED twins, which are refreshed
+        once, in ``step()``.  Conditions (else this returns False and ``step()`` works as before): GPU, replicated
+        optimizer state, a device-ordered reduction handle (RCCL, or a single rank), no conv3 recompute.  The caller
+        keeps ``lr`` / ``grad_scale`` fixed from ``backward()`` to ``step()`` and does not use ``clip_grad_norm`` (the
+        global norm needs every gradient before any update): ``train.run_dp`` enables this mode only without clipping
+        and without an LR schedule, ``bench.py`` by default (``--no-opt-overlap`` turns it off)."""
+        from .ops import block as _block
+        ok = (enabled and self.flat.device.type == "cuda" and dp.shards is None and type(self) is FusedSGD
+              and (dp.world_size == 1 or getattr(dp.comm, "backend", "") == "nccl")
+              and _block.RECOMPUTE_MIN_BYTES > (1 << 50))
+        if not ok:
+            dp.bucket_hook = None
+            self._ov = None
+            return False
+        self._ov = {"stream": torch.cuda.Stream(device=self.flat.device), "done": [], "tables": {}}
+        dp.bucket_hook = self._step_bucket
+        return True
+
+    def _range_args(self, start: int, end: int):
+        """Weight-decay table of flat[start:end), relative to start (cached per range)."""
+        key = (start, end)
+        t = self._ov["tables"].get(key) if self._ov is not None else None
+        if t is None:
+            segs = [(max(a, start) - start, min(b, end) - start, w) for a, b, w in self.segments if max(a, start) < min(b, end)]
+            ends = wds = None
+            if len(segs) > 1:
+                ends = torch.tensor([b for _, b, _ in segs], dtype=torch.int64, device=self.flat.device)
+                wds = torch.tensor([w for _, _, w in segs], dtype=torch.float32, device=self.flat.device)
+            t = (segs[0][2], ends, wds)
+            if self._ov is not None:
+                self._ov["tables"][key] = t
+        return t
+
+    @torch.no_grad()
+    def _launch_range(self, C, start: int, end: int, gs: float, scale_dev=None) -> None:
+        f = self.flat
+        wd0, ends, wds = self._range_args(start, end)
+        C.sgd_momentum(f.master[start:end], f.grad[start:end],
+                       None if self.momentum_buf is None else self.momentum_buf[start:end],
+                       None if f.lp is None else f.lp[start:end], self.lr, self.momentum, wd0, gs, True, self.nesterov,
+                       ends, wds, scale_dev)
+
+    def _step_bucket(self, b) -> None:
+        if self._ov is None or self.clip_coef is not None:
+            return
+        from .ops import _ext, side
+        f = self.flat
+        st = self._ov["stream"]
+        st.wait_stream(torch.cuda.current_stream(f.device))    # everything enqueued on the compute stream so far
+        s = side.for_device(f.device.index if f.device.index is not None else torch.cuda.current_device())
+        if s is not None and getattr(s, "stream", None) is not None:
+            st.wait_stream(s.stream)                           # ... and the weight-gradient kernels on the side stream
+        with torch.cuda.stream(st):
+            if b.work is not None:
+                b.work.wait()                                  # the bucket's reduction (device-side wait on RCCL's stream)
+            self._launch_range(_ext.load(), b.start, b.end, self.grad_scale)
+        self._ov["done"].append((b.start, b.end))
 
     def _segments(self, no_decay):
         f = self.flat
@@ -61,6 +126,19 @@ class FusedSGD:
             from .ops import _ext, side
             side.join(f.device)             # weight gradients may still be in flight on the side stream
             C = _ext.load()
+            if self._ov is not None and self._ov["done"]:
+                # overlapped mode: most (usually all) buckets were updated during backward; the rest now
+                torch.cuda.current_stream(f.device).wait_stream(self._ov["stream"])
+                pos = 0
+                for a, b in sorted(self._ov["done"]) + [(f.total, f.total)]:
+                    if a > pos:
+                        self._launch_range(C, pos, a, gs, self.clip_coef)
+                    pos = max(pos, b)
+                self._ov["done"] = []
+                f.refresh_transposed()
+                self.clip_coef = None
+                self.steps += 1
+                return
             if len(self.segments) > 1 and self._seg_ends is None:       # device-side weight-decay table, built once
                 self._seg_ends = torch.tensor([b for _, b, _ in self.segments], dtype=torch.int64, device=f.device)
                 self._seg_wd = torch.tensor([w for _, _, w in self.segments], dtype=torch.float32, device=f.device)

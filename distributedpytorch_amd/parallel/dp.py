@@ -81,6 +81,9 @@ class DataParallel:
         self._launched: List[Bucket] = []
         self._next_bucket = 0
         self.stats = {"allreduce_calls": 0, "allreduce_bytes": 0}
+        # called with a bucket right after its reduction has been ISSUED (b.work is the handle): optim.FusedSGD's
+        # overlapped mode updates the bucket's parameters behind it, while backward is still running
+        self.bucket_hook = None
         for p in self.flat.params:
             p.register_post_accumulate_grad_hook(self._on_grad)
         if use_sink and self.flat.device.type == "cuda":
@@ -181,6 +184,8 @@ class DataParallel:
         self._launched.append(b)
         self.stats["allreduce_calls"] += 1
         self.stats["allreduce_bytes"] += view.numel() * 4
+        if self.bucket_hook is not None:
+            self.bucket_hook(b)
 
     # ------------------------------------------------------------------ step boundary
     def finish(self) -> None:

@@ -259,6 +259,54 @@ def test_gpt2_tiny_trains_on_gpu():
     assert losses[-1] < losses[0]
 
 
+@pytest.mark.parametrize("which", ["tiny_resnet", "gpt2_tiny"])
+def test_optimizer_overlapped_with_backward_follows_the_same_trajectory(which):
+    """``FusedSGD.overlap_with_backward``: buckets updated on their own stream behind their reduction, while backward is
+    still running, must give the parameters the single end-of-step launch gives (same arithmetic, earlier).  Small
+    buckets so that several updates really happen inside backward; momentum + weight decay + per-segment decay table."""
+    from distributedpytorch_amd.optim import FusedSGD
+    from distributedpytorch_amd.parallel.dp import DataParallel
+
+    def run(overlap):
+        torch.manual_seed(7)
+        if which == "tiny_resnet":
+            from distributedpytorch_amd.models import resnet
+            m = resnet.tiny_resnet().to(DEV).train()
+            g = torch.Generator(device=DEV).manual_seed(3)
+            x = torch.randn(16, 3, 64, 64, generator=g, device=DEV)
+            y = torch.randint(0, 16, (16,), generator=g, device=DEV)
+        else:
+            from distributedpytorch_amd.models import gpt2
+            m = gpt2.gpt2_tiny(n_layer=2, n_embd=128, n_head=2, vocab=504, n_positions=128).to(DEV).train()
+            g = torch.Generator(device=DEV).manual_seed(3)
+            x = torch.randint(0, 504, (2, 128), generator=g, device=DEV)
+            y = torch.randint(0, 504, (2, 128), generator=g, device=DEV)
+        dp = DataParallel(m, bucket_mb=0.05, first_bucket_mb=0.02)
+        opt = FusedSGD(dp.flat, lr=0.05, momentum=0.9, weight_decay=1e-3)
+        opt.grad_scale = dp.grad_scale
+        assert opt.overlap_with_backward(dp, enabled=overlap) == overlap
+        assert len(dp.buckets) >= 3
+        losses = []
+        for _ in range(5):
+            loss = m.loss(x, y)
+            loss.backward()
+            dp.finish()
+            opt.step()
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        assert float(dp.flat.grad.abs().max()) == 0.0                     # every gradient consumed and zeroed
+        return losses, dp.flat.master.clone(), opt.momentum_buf.clone()
+
+    l0, p0, m0 = run(False)
+    l1, p1, m1 = run(True)
+    # float atomics in the weight-gradient kernels make two runs differ in the last bits; the trajectories must agree
+    # as closely as two PLAIN runs do
+    l2, p2, m2 = run(False)
+    ref = float((p0 - p2).abs().max())
+    assert float((p0 - p1).abs().max()) <= max(10 * ref, 1e-5), (float((p0 - p1).abs().max()), ref)
+    assert max(abs(a - b) for a, b in zip(l0, l1)) <= max(10 * max(abs(a - b) for a, b in zip(l0, l2)), 1e-3)
+
+
 def test_mnist_hipgraph_step_matches_eager_and_draws_fresh_masks():
     """Forward+backward captured in a hipGraph: gradients equal the eager step's (same device-counter
     dropout stream), and a second replay draws different dropout masks."""
