@@ -52,7 +52,9 @@ def parse():
     p.add_argument("--no-sink", action="store_true")
     p.add_argument("--shard-optimizer", action="store_true", help="ZeRO stage 1: optimizer state sharded over the DP ranks")
     p.add_argument("--backend", default="auto")
-    p.add_argument("--no-opt-overlap", action="store_true", help="run the optimizer as one launch after backward instead of per bucket behind its all-reduce")
+    p.add_argument("--opt-overlap", default="auto", choices=["auto", "on", "off"],
+                   help="optimizer per bucket behind its all-reduce, during backward (optim.FusedSGD.overlap_with_backward); "
+                        "auto = on for gpt2 (+0.9 %% on one GPU), off for the ResNets (-0.3 %%: their step is HBM-bound throughout)")
     p.add_argument("--breakdown", action="store_true",
                    help="HIP-event phase timers: forward / backward / exposed communication / optimizer per step, added to the JSON")
     p.add_argument("--comm", default=None, choices=["native", "c10d"], help="collective layer under RCCL (default: DPA_COMM or native)")
@@ -196,7 +198,8 @@ def main():
         opt.grad_scale = dp.grad_scale
         if not args.shard_optimizer and args.model != "mnist":
             # every bucket's update runs behind its all-reduce while backward continues (optim.FusedSGD.overlap_with_backward)
-            cfg["optimizer_overlap"] = opt.overlap_with_backward(dp, enabled=not args.no_opt_overlap)
+            want = args.opt_overlap == "on" or (args.opt_overlap == "auto" and args.model == "gpt2")
+            cfg["optimizer_overlap"] = opt.overlap_with_backward(dp, enabled=want)
 
         graphed = None
         if args.model == "mnist" and not args.no_graph:

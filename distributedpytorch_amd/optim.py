@@ -49,7 +49,7 @@ class FusedSGD:
         optimizer state, a device-ordered reduction handle (RCCL, or a single rank), no conv3 recompute.  The caller
         keeps ``lr`` / ``grad_scale`` fixed from ``backward()`` to ``step()`` and does not use ``clip_grad_norm`` (the
         global norm needs every gradient before any update): ``train.run_dp`` enables this mode only without clipping
-        and without an LR schedule, ``bench.py`` by default (``--no-opt-overlap`` turns it off)."""
+        and without an LR schedule, ``bench.py`` for GPT-2 (``--opt-overlap on|off|auto``)."""
         from .ops import block as _block
         ok = (enabled and self.flat.device.type == "cuda" and dp.shards is None and type(self) is FusedSGD
               and (dp.world_size == 1 or getattr(dp.comm, "backend", "") == "nccl")
@@ -58,7 +58,7 @@ class FusedSGD:
             dp.bucket_hook = None
             self._ov = None
             return False
-        self._ov = {"stream": torch.cuda.Stream(device=self.flat.device), "done": [], "tables": {}}
+        self._ov = {"stream": torch.cuda.Stream(device=self.flat.device), "done": [], "tables": {}, "twins": 0}
         dp.bucket_hook = self._step_bucket
         return True
 
@@ -97,6 +97,13 @@ class FusedSGD:
         if s is not None and getattr(s, "stream", None) is not None:
             st.wait_stream(s.stream)                           # ... and the weight-gradient kernels on the side stream
         with torch.cuda.stream(st):
+            # the transposed twins of the buckets updated EARLIER: the last kernel of this backward that reads them (the
+            # input-gradient GEMM of a bucket's earliest layer, enqueued after that layer's weight-gradient kernel, i.e.
+            # possibly after the bucket's hook) is on the compute stream by now, and this stream has just been ordered
+            # behind the compute stream
+            for a, e in self._ov["done"][self._ov["twins"]:]:
+                f.refresh_transposed_range(a, e)
+            self._ov["twins"] = len(self._ov["done"])
             if b.work is not None:
                 b.work.wait()                                  # the bucket's reduction (device-side wait on RCCL's stream)
             self._launch_range(_ext.load(), b.start, b.end, self.grad_scale)
@@ -133,9 +140,11 @@ class FusedSGD:
                 for a, b in sorted(self._ov["done"]) + [(f.total, f.total)]:
                     if a > pos:
                         self._launch_range(C, pos, a, gs, self.clip_coef)
+                        f.refresh_transposed_range(pos, a)
                     pos = max(pos, b)
-                self._ov["done"] = []
-                f.refresh_transposed()
+                for a, b in self._ov["done"][self._ov["twins"]:]:      # buckets updated during backward, twins still old
+                    f.refresh_transposed_range(a, b)
+                self._ov["done"], self._ov["twins"] = [], 0
                 self.clip_coef = None
                 self.steps += 1
                 return

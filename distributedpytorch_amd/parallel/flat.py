@@ -95,6 +95,7 @@ class FlatParams:
                 self.lp_t = torch.zeros(self.total, dtype=self.lp_dtype, device=device)
                 self._tr_table = torch.tensor(rows, dtype=torch.int64, device=device)
                 self._tr_tiles = tiles
+                self._tr_rows, self._tr_tile_edge, self._tr_sub = rows, tt, {}
         self.refresh_lp()
         self._bind_shadows()
 
@@ -152,6 +153,24 @@ class FlatParams:
             return
         from ..ops import _ext
         _ext.load().transpose_filters_batched(self.lp, self.lp_t, self._tr_table, self._tr_tiles)
+
+    def refresh_transposed_range(self, start: int, end: int) -> None:
+        """The same for the filters that lie in ``flat[start:end)`` only (a gradient bucket: ``optim.FusedSGD``'s
+        overlapped mode refreshes a bucket's twins while backward is still running).  Sub-tables are cached."""
+        if self.lp_t is None:
+            return
+        key = (start, end)
+        sub = self._tr_sub.get(key)
+        if sub is None:
+            rows, tiles, tt = [], 0, self._tr_tile_edge
+            for src, dst, K, RS, C, _ in self._tr_rows:
+                if start <= src < end:
+                    rows.append([src, dst, K, RS, C, tiles])
+                    tiles += ((K + tt - 1) // tt) * ((C + tt - 1) // tt) * RS
+            sub = self._tr_sub[key] = (torch.tensor(rows, dtype=torch.int64, device=self.device) if rows else None, tiles)
+        if sub[0] is not None:
+            from ..ops import _ext
+            _ext.load().transpose_filters_batched(self.lp, self.lp_t, sub[0], sub[1])
 
     # ------------------------------------------------------------------ grads
     def zero_grad(self) -> None:
