@@ -208,6 +208,9 @@ def main():
             from distributedpytorch_amd.parallel.graph import GraphedStep
             model._drop.use_device_counter(device)
             graphed = GraphedStep(dp, lambda xx, yy: model.loss(xx, yy), (x, y))   # Net.loss bumps the dropout counter itself
+            # the synthetic batch lives in the graph's input buffers, as the other workloads' batch lives in one device
+            # tensor that every step reads: no per-step device-to-device copy of data that never changes
+            x, y = graphed.static_inputs
             cfg["hipgraph"] = True
 
         from distributedpytorch_amd.metrics import PhaseTimer
