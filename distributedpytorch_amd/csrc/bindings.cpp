@@ -46,9 +46,10 @@ struct DetStats {
 static int64_t det_slots(int64_t rows_out, int64_t stride) { return ((rows_out + 63) / 64 + 1) * stride * stride; }
 
 // `addend` (bf16, the output's shape): y = conv(x) + bias + addend - a residual connection in the GEMM epilogue.
+// stride_w / pad_w >= 0: the width axis has its own stride / padding (the pair-packed stem convolution).
 std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias, int64_t stride,
                                int64_t pad, int64_t act, bool want_stats, const c10::optional<Tensor>& stats_buf,
-                               const c10::optional<Tensor>& addend, bool gelu_twin) {
+                               const c10::optional<Tensor>& addend, bool gelu_twin, int64_t stride_w, int64_t pad_w, int64_t out_w) {
     CHECK_BF16(x); CHECK_BF16(w);
     TORCH_CHECK(x.dim() == 4 && w.dim() == 4, "conv_fprop: x and w must be 4-D (NHWC / KRSC)");
     const int64_t N = x.size(0), H = x.size(1), W = x.size(2), C = x.size(3);
@@ -56,7 +57,14 @@ std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::opti
     TORCH_CHECK(w.size(3) == C, "conv_fprop: channel mismatch ", w.size(3), " vs ", C);
     TORCH_CHECK(C % 8 == 0 && K % 8 == 0, "conv_fprop: C and K must be multiples of 8 (pad channels)");
     TORCH_CHECK(stride >= 1 && pad >= 0, "bad stride/pad");
-    const int64_t Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    const bool asym = stride_w >= 0 || pad_w >= 0;
+    TORCH_CHECK(!asym || (stride_w >= 1 && pad_w >= 0), "conv_fprop: stride_w and pad_w go together");
+    const int64_t Ho = (H + 2 * pad - R) / stride + 1,
+                  Wo_full = asym ? (W + 2 * pad_w - S) / stride_w + 1 : (W + 2 * pad - S) / stride + 1;
+    // out_w (asym only): fewer output columns than the padding would allow (the packed stem pads 2 pairs on both sides
+    // but its last output column needs only one)
+    TORCH_CHECK(out_w < 0 || (asym && out_w >= 1 && out_w <= Wo_full), "conv_fprop: out_w");
+    const int64_t Wo = out_w > 0 ? out_w : Wo_full;
     TORCH_CHECK(Ho > 0 && Wo > 0, "conv_fprop: empty output");
     TORCH_CHECK(x.numel() < (1ll << 30) && w.numel() < (1ll << 30) && N * Ho * Wo * K < (1ll << 31) - 16,
                 "conv_fprop: operands must have fewer than 2^31 elements (32-bit gather offsets)");
@@ -95,6 +103,7 @@ std::vector<Tensor> conv_fprop(const Tensor& x, const Tensor& w, const c10::opti
     }
     a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.Ho = Ho; a.Wo = Wo;
     a.stride = stride; a.pad = pad; a.mode = 0; a.act = act;
+    a.asym = asym ? 1 : 0; a.stride_w = asym ? (int)stride_w : 0; a.pad_w = asym ? (int)pad_w : 0;
     Tensor y_act;
     if (gelu_twin) {      // second output gelu_tanh(y): the next GEMM's operand, y itself stays for the GELU's backward
         TORCH_CHECK(!want_stats && act == 0, "conv_fprop: gelu_twin goes with a linear epilogue and no statistics");
@@ -344,14 +353,19 @@ Tensor tail_bwd(const Tensor& dout, const c10::optional<Tensor>& kout, const Ten
 // dw [K,R,S,C] fp32 += wgrad(x, dy).  dw must be initialised by the caller.  With dbias (fp32 [K]) the bias
 // gradient dbias += column sums of dy is produced too: inside the wgrad kernel where that variant exists, else by
 // the column-sum kernels.
-void conv_wgrad(const Tensor& x, const Tensor& dy, Tensor& dw, int64_t stride, int64_t pad, const c10::optional<Tensor>& dbias) {
+void conv_wgrad(const Tensor& x, const Tensor& dy, Tensor& dw, int64_t stride, int64_t pad, const c10::optional<Tensor>& dbias,
+                int64_t stride_w, int64_t pad_w) {
     CHECK_BF16(x); CHECK_BF16(dy); CHECK_F32(dw);
     TORCH_CHECK(x.dim() == 4 && dy.dim() == 4 && dw.dim() == 4, "conv_wgrad: 4-D tensors expected");
     const int64_t N = x.size(0), H = x.size(1), W = x.size(2), C = x.size(3);
     const int64_t Ho = dy.size(1), Wo = dy.size(2), K = dy.size(3);
     const int64_t R = dw.size(1), S = dw.size(2);
     TORCH_CHECK(dy.size(0) == N && dw.size(0) == K && dw.size(3) == C, "conv_wgrad: shape mismatch");
-    TORCH_CHECK((H + 2 * pad - R) / stride + 1 == Ho && (W + 2 * pad - S) / stride + 1 == Wo, "conv_wgrad: geometry mismatch");
+    const bool asym = stride_w >= 0 || pad_w >= 0;
+    TORCH_CHECK(!asym || (stride_w >= 1 && pad_w >= 0), "conv_wgrad: stride_w and pad_w go together");
+    TORCH_CHECK((H + 2 * pad - R) / stride + 1 == Ho &&
+                (asym ? Wo >= 1 && Wo <= (W + 2 * pad_w - S) / stride_w + 1 : (W + 2 * pad - S) / stride + 1 == Wo),
+                "conv_wgrad: geometry mismatch");
     TORCH_CHECK(C % 8 == 0 && K % 8 == 0, "conv_wgrad: channels must be multiples of 8");
     TORCH_CHECK(x.numel() < (1ll << 30) - (1ll << 24) && dy.numel() < (1ll << 30) - (1ll << 24),
                 "conv_wgrad: operands must stay below 2^31 bytes (32-bit buffer offsets)");
@@ -359,6 +373,7 @@ void conv_wgrad(const Tensor& x, const Tensor& dy, Tensor& dw, int64_t stride, i
     dpa::WgradArgs a{};
     a.x = x.data_ptr(); a.dy = dy.data_ptr(); a.dw = dw.data_ptr<float>();
     a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = pad;
+    a.asym = asym ? 1 : 0; a.stride_w = asym ? (int)stride_w : 0; a.pad_w = asym ? (int)pad_w : 0;
     a.dbias = nullptr;
     const bool want_bias = dbias.has_value() && dbias->defined();
     if (want_bias) {
@@ -652,6 +667,32 @@ Tensor nchw_to_nhwc_pad(const Tensor& x, int64_t Cpad) {
     dpa::nchw_to_nhwc_pad(x.data_ptr(), x.scalar_type() == at::kBFloat16, y.data_ptr(), x.size(0), x.size(1), x.size(2),
                           x.size(3), Cpad, cur_stream());
     return y;
+}
+
+// pair-packed stem: see elementwise.hip
+Tensor nchw_to_pairs(const Tensor& x) {
+    CHECK_DEV(x); CHECK_CONTIG(x);
+    TORCH_CHECK(x.dim() == 4 && x.size(1) >= 1 && x.size(1) <= 3 && x.size(3) % 2 == 0, "nchw_to_pairs: NCHW, C <= 3, even W");
+    TORCH_CHECK(x.scalar_type() == at::kFloat || x.scalar_type() == at::kBFloat16, "fp32 or bf16 input");
+    Guard g(x);
+    Tensor y = torch::empty({x.size(0), x.size(2), x.size(3) / 2, 8}, x.options().dtype(at::kBFloat16));
+    dpa::nchw_to_pairs(x.data_ptr(), x.scalar_type() == at::kBFloat16, y.data_ptr(), x.size(0), x.size(1), x.size(2), x.size(3), cur_stream());
+    return y;
+}
+Tensor stem_pack_filter(const Tensor& w, int64_t C) {
+    CHECK_BF16(w);
+    TORCH_CHECK(w.dim() == 4 && w.size(2) == 7 && w.size(3) == 8 && C >= 1 && C <= 3, "stem_pack_filter: [K,R,7,8] filter, C <= 3");
+    Guard g(w);
+    Tensor wp = torch::empty({w.size(0), w.size(1), 4, 8}, w.options());
+    dpa::stem_pack_filter(w.data_ptr(), wp.data_ptr(), w.size(0) * w.size(1), C, cur_stream());
+    return wp;
+}
+void stem_unpack_dw(const Tensor& dwp, Tensor& dw, int64_t C) {
+    CHECK_F32(dwp); CHECK_F32(dw);
+    TORCH_CHECK(dwp.dim() == 4 && dw.dim() == 4 && dwp.size(2) == 4 && dwp.size(3) == 8 && dw.size(2) == 7 && dw.size(3) == 8 &&
+                dwp.size(0) == dw.size(0) && dwp.size(1) == dw.size(1) && C >= 1 && C <= 3, "stem_unpack_dw: shapes");
+    Guard g(dw);
+    dpa::stem_unpack_dw(dwp.data_ptr<float>(), dw.data_ptr<float>(), dw.size(0) * dw.size(1), C, cur_stream());
 }
 
 Tensor ew2(const Tensor& a, const Tensor& b, int64_t op) {
@@ -982,7 +1023,8 @@ void bind_rccl(pybind11::module_& m);         // rccl_comm.cpp
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "distributedpytorch_amd gfx950 kernels";
     m.def("conv_fprop", &conv_fprop, py::arg("x"), py::arg("w"), py::arg("bias"), py::arg("stride"), py::arg("pad"), py::arg("act"),
-          py::arg("want_stats"), py::arg("stats_buf"), py::arg("addend") = py::none(), py::arg("gelu_twin") = false);
+          py::arg("want_stats"), py::arg("stats_buf"), py::arg("addend") = py::none(), py::arg("gelu_twin") = false,
+          py::arg("stride_w") = -1, py::arg("pad_w") = -1, py::arg("out_w") = -1);
     m.def("conv_dgrad", &conv_dgrad, py::arg("dy"), py::arg("wt"), py::arg("H"), py::arg("W"), py::arg("stride"), py::arg("pad"),
           py::arg("addend"), py::arg("addend_mask"), py::arg("bn_x") = py::none(), py::arg("bn_mask") = py::none(),
           py::arg("bn_stats") = py::none(), py::arg("gelu_x") = py::none());
@@ -999,7 +1041,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("conv_bnb_apply", &conv_bnb_apply);
     m.def("bn_bwd_coefs", &bn_bwd_coefs);
     m.def("conv_wgrad", &conv_wgrad, py::arg("x"), py::arg("dy"), py::arg("dw"), py::arg("stride"), py::arg("pad"),
-          py::arg("dbias") = py::none());
+          py::arg("dbias") = py::none(), py::arg("stride_w") = -1, py::arg("pad_w") = -1);
     m.def("transpose_filter", &transpose_filter);
     m.def("transpose_filters_batched", &transpose_filters_batched);
     m.def("transpose_tile", [] { return dpa::transpose_tile(); });
@@ -1017,6 +1059,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("avgpool_fwd", &avgpool_fwd);
     m.def("avgpool_bwd", &avgpool_bwd);
     m.def("nchw_to_nhwc_pad", &nchw_to_nhwc_pad);
+    m.def("nchw_to_pairs", &nchw_to_pairs);
+    m.def("stem_pack_filter", &stem_pack_filter);
+    m.def("stem_unpack_dw", &stem_unpack_dw);
     m.def("ew2", &ew2);
     m.def("softmax_ce_fwd", &softmax_ce_fwd);
     m.def("softmax_ce_bwd", &softmax_ce_bwd);

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, igemm_waves_per_simd(WP, ONE, STG)) void conv_
         const unsigned n = mm / (unsigned)PHW;
         const unsigned rem = mm - n * (unsigned)PHW;
         const int ho = (int)(rem / (unsigned)PW), wo = (int)(rem - (rem / (unsigned)PW) * (unsigned)PW);
-        if (MODE == 0)      { hi0[i] = ho * a.stride - a.pad; wi0[i] = wo * a.stride - a.pad; }
+        if (MODE == 0)      { hi0[i] = ho * a.stride - a.pad; wi0[i] = a.asym ? wo * a.stride_w - a.pad_w : wo * a.stride - a.pad; }
         else if (MODE == 1) { hi0[i] = ho + a.pad;            wi0[i] = wo + a.pad; }
         else                { hi0[i] = (ho * a.stride + ph0 + a.pad - r0) / a.stride;   // exact division
                               wi0[i] = (wo * a.stride + pw0 + a.pad - s0) / a.stride; }

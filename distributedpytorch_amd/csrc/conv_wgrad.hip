@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, DMA ? 3 : 2) void conv_wgrad_kernel(WgradArgs 
                 b_off[i] += b_step;                                                              \
             } else {                                                                             \
                 const int hi = pho[i] * a.stride - a.pad + fr;                                   \
-                const int wi = pwo[i] * a.stride - a.pad + fs;                                   \
+                const int wi = (a.asym ? pwo[i] * a.stride_w - a.pad_w : pwo[i] * a.stride - a.pad) + fs; \
                 const bool ok = prem[i] > 0 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W; \
                 const unsigned off = ((unsigned)((pn[i] * a.H + hi) * a.W + wi) * (unsigned)a.C + (unsigned)fc) * 2u; \
                 BREG[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? off : OOB, 0, 0);      \
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, DMA ? 3 : 2) void conv_wgrad_kernel(WgradArgs 
                 b_off[i] += b_step;                                                              \
             } else {                                                                             \
                 const int hi = pho[i] * a.stride - a.pad + fr;                                   \
-                const int wi = pwo[i] * a.stride - a.pad + fs;                                   \
+                const int wi = (a.asym ? pwo[i] * a.stride_w - a.pad_w : pwo[i] * a.stride - a.pad) + fs; \
                 const bool ok = prem[i] > 0 && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W; \
                 const unsigned off = ((unsigned)((pn[i] * a.H + hi) * a.W + wi) * (unsigned)a.C + (unsigned)fc) * 2u; \
                 dma16<true>(xrs, xrs4, bs_ + i * 4096, ok ? off : OOB);                          \

@@ -297,6 +297,53 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ m
     GRID_STRIDE(i, n) mask[i] = dropout_keep(seed, offset, (uint64_t)i, p, keep_scale);
 }
 
+// ------------------------------------------------------------------ pair-packed stem (3-channel images)
+// The 7x7 / stride 2 / pad 3 stem convolution on a 3-channel image padded to 8 channels spends 5/8 of its MFMA work and
+// gather traffic on zeros.  Packed as PIXEL PAIRS - y[n][h][j][0:3] = pixel (h, 2j), y[n][h][j][3:6] = pixel (h, 2j+1),
+// channels 6-7 zero - the same convolution is 7 x 4 taps over [N, H, W/2, 8] with stride (2, 1) and padding (3, 2):
+// output column w covers input columns 2w-3 .. 2w+3 = pairs w-2 (odd half), w-1, w, w+1.  224 instead of 392 GEMM-K,
+// half the input bytes.  The filter is re-packed to [K][7][4][8] (slot (sp, half) <- tap s = 2 sp + half - 1, none for
+// s = -1) and its gradient unpacked back into the [K][7][7][8] layout the parameter has.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_pairs_kernel(const T* __restrict__ x, unsigned short* __restrict__ y, int N, int C,
+                                                            int H, int W) {
+    const int Wp = W / 2;
+    const long total = (long)N * H * Wp, HW = (long)H * W;
+    GRID_STRIDE(i, total) {
+        const long n = i / ((long)H * Wp);
+        const long r = i - n * (long)H * Wp;            // h * Wp + j
+        const long h = r / Wp, j = r - h * Wp;
+        float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = 0; c < C; ++c) {
+            const T* p = x + (n * C + c) * HW + h * W + 2 * j;
+            if constexpr (sizeof(T) == 4) { f[c] = p[0]; f[C + c] = p[1]; }
+            else { f[c] = bf16_to_float(p[0]); f[C + c] = bf16_to_float(p[1]); }
+        }
+        *(uint4*)(y + i * 8) = pack8(f);
+    }
+}
+
+// w [K][R][7][8] (3 real channels) -> wp [K][R][4][8]
+__global__ __launch_bounds__(256) void stem_pack_filter_kernel(const unsigned short* __restrict__ w, unsigned short* __restrict__ wp,
+                                                               int KR, int C) {
+    const int total = KR * 4 * 8;
+    GRID_STRIDE(i, total) {
+        const int ch = (int)(i & 7), sp = (int)((i >> 3) & 3), kr = (int)(i >> 5);
+        const int half = ch / C, c = ch - half * C, s = 2 * sp + half - 1;
+        wp[i] = (half < 2 && s >= 0 && s < 7) ? w[(kr * 7 + s) * 8 + c] : (unsigned short)0;
+    }
+}
+
+// dw [K][R][7][8] (fp32) += unpacked dwp [K][R][4][8]
+__global__ __launch_bounds__(256) void stem_unpack_dw_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int KR, int C) {
+    const int total = KR * 7 * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C), s = (int)((i / C) % 7), kr = (int)(i / (7 * C));
+        const int sp = (s + 1) >> 1, half = (s + 1) & 1;
+        dw[(kr * 7 + s) * 8 + c] += dwp[(kr * 4 + sp) * 8 + half * C + c];
+    }
+}
+
 // element dropout of a bf16 tensor with the mask drawn in line (no mask tensor), optionally added to a residual
 __global__ __launch_bounds__(256) void dropout_bf16_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ addend,
                                                            unsigned short* __restrict__ y, long nchunks, float p, uint64_t seed,
@@ -439,6 +486,23 @@ void dropout_bf16(const void* x, const void* addend, void* y, long n, float p, u
     const long nchunks = n / 8;
     hipLaunchKernelGGL(dropout_bf16_kernel, dim3(grid_for(nchunks)), dim3(256), 0, st, (const unsigned short*)x,
                        (const unsigned short*)addend, (unsigned short*)y, nchunks, p, seed, offset);
+}
+
+void nchw_to_pairs(const void* x, int x_is_bf16, void* y, int N, int C, int H, int W, hipStream_t st) {
+    const long total = (long)N * H * (W / 2);
+    if (x_is_bf16)
+        hipLaunchKernelGGL((nchw_to_pairs_kernel<unsigned short>), dim3(grid_for(total)), dim3(256), 0, st,
+                           (const unsigned short*)x, (unsigned short*)y, N, C, H, W);
+    else
+        hipLaunchKernelGGL((nchw_to_pairs_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, (const float*)x,
+                           (unsigned short*)y, N, C, H, W);
+}
+void stem_pack_filter(const void* w, void* wp, int KR, int C, hipStream_t st) {
+    hipLaunchKernelGGL(stem_pack_filter_kernel, dim3(grid_for((long)KR * 32)), dim3(256), 0, st, (const unsigned short*)w,
+                       (unsigned short*)wp, KR, C);
+}
+void stem_unpack_dw(const float* dwp, float* dw, int KR, int C, hipStream_t st) {
+    hipLaunchKernelGGL(stem_unpack_dw_kernel, dim3(grid_for((long)KR * 7 * C)), dim3(256), 0, st, dwp, dw, KR, C);
 }
 
 }  // namespace dpa

@@ -31,6 +31,8 @@ struct ConvArgs {
                                        // elements of addend count as 0 (ReLU gradient of the residual join)
     int N, H, W, C, K, R, S, Ho, Wo;
     int stride, pad;
+    int asym, stride_w, pad_w;   // asym != 0 (fprop only): the WIDTH axis uses stride_w / pad_w instead of stride / pad
+                                 // (the pair-packed stem: 7 x 4 taps, stride 2 x 1, pad 3 x 2 - ops/block.py)
     int mode;           // 0 fprop, 1 dgrad
     int act;            // 0 none, 1 relu, 2 gelu(tanh)
     // Fused BatchNorm epilogues (fprop only), c = this conv's bf16-rounded output, never written when epi != 0:
@@ -68,6 +70,7 @@ struct WgradArgs {
     float* dw;        // fp32 [K, R, S, C]
     int N, H, W, C, K, R, S, Ho, Wo;
     int stride, pad;
+    int asym, stride_w, pad_w;   // as in ConvArgs
     float* dbias;     // optional fp32 [K]: += column sums of dy (bias gradient), computed on the MFMA beside dw
 };
 void conv_wgrad(const WgradArgs& a, hipStream_t st);
@@ -148,6 +151,11 @@ void avgpool_fwd(const void* x, void* y, int N, int HW, int C, hipStream_t st);
 void avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, hipStream_t st);
 // NCHW (fp32 or bf16) -> NHWC bf16 with channel padding to Cpad
 void nchw_to_nhwc_pad(const void* x, int x_is_bf16, void* y, int N, int C, int H, int W, int Cpad, hipStream_t st);
+// pair-packed stem (elementwise.hip): NCHW image (C <= 3, W even) -> [N, H, W/2, 8] pixel pairs; filter [K][R][7][8] ->
+// [K][R][4][8]; filter gradient back (dw += unpack(dwp)).  KR = K * R.
+void nchw_to_pairs(const void* x, int x_is_bf16, void* y, int N, int C, int H, int W, hipStream_t st);
+void stem_pack_filter(const void* w, void* wp, int KR, int C, hipStream_t st);
+void stem_unpack_dw(const float* dwp, float* dw, int KR, int C, hipStream_t st);
 // elementwise on bf16: y = a + b ; relu variants
 void add_bf16(const void* a, const void* b, void* y, long n, hipStream_t st);
 void add_relu_fwd(const void* a, const void* b, void* y, long n, hipStream_t st);

@@ -56,6 +56,8 @@ class Stem(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dim() == 4 and x.shape[1] == 3:          # NCHW image batch -> kernel layout
+            if _block.can_fuse_stem_packed(self, x):
+                return _block.stem_packed(self, x)     # pixel-pair layout: the 7x7 conv as 7 x 4 taps (ops/block.py)
             x = ops.to_nhwc(x, self.conv1.in_padded)
         if _block.can_fuse_stem(self, x):
             return _block.stem(self, x)            # one autograd node; the 112x112 activation is never written

@@ -411,6 +411,75 @@ class _StemFn(torch.autograd.Function):
         return (None, None, *grads)         # the image batch needs no gradient
 
 
+class _StemPackedFn(torch.autograd.Function):
+    """``_StemFn`` on the PAIR-PACKED image (csrc/elementwise.hip): the 3-channel image travels as [N, H, W/2, 8] pixel
+    pairs and the 7x7 / stride 2 convolution runs as 7 x 4 taps with stride (2, 1), padding (3, 2) - 224 instead of 392
+    GEMM-K for the forward conv and for its weight gradient (the last kernel of the step, with nothing beside it)."""
+
+    @staticmethod
+    def forward(ctx, xp, stem, *params):
+        C = _ext.load()
+        conv, bn = stem.conv1, stem.bn1
+        wp = C.stem_pack_filter(conv.weight_lp, 3)
+        c1, stats = C.conv_fprop(xp, wp, None, 2, 3, 0, True, bn.stats_buffer(xp.device), None, False, 1, 2, xp.shape[2])
+        P = c1.numel() // c1.shape[-1]
+        mean, invstd, scale, shift = C.bn_finalize(stats, P, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                                                   bn.running_var, bn.momentum, bn.eps, True)
+        y, idx = C.bn_relu_maxpool_fwd(c1, scale, shift)
+        ctx.save_for_backward(xp, c1, mean, invstd, idx)
+        ctx.stem = stem
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        C = _ext.load()
+        xp, c1, mean, invstd, idx = ctx.saved_tensors
+        conv, bn = ctx.stem.conv1, ctx.stem.bn1
+        grads = [None, None, None]          # conv1.weight bn1.weight bn1.bias
+        tg, tb = _sink.target(bn.weight), _sink.target(bn.bias)
+        sunk = tg is not None and tb is not None
+        dc1, dg, db = C.pool_bn_backward(dy.contiguous(), idx, c1, bn.weight.detach(), mean, invstd,
+                                         tg if sunk else None, tb if sunk else None, bn.stats_buffer_bwd(dy.device))
+        if sunk:
+            _sink.ready(bn.weight); _sink.ready(bn.bias)
+        else:
+            grads[1], grads[2] = dg, db
+        K, R = conv.weight_lp.shape[0], conv.weight_lp.shape[1]
+        tgt = _sink.target(conv.weight)
+        dst = tgt if tgt is not None else torch.zeros(conv.weight_lp.shape, dtype=torch.float32, device=dy.device)
+
+        def wgrad():
+            dwp = torch.zeros(K, R, 4, 8, dtype=torch.float32, device=dy.device)
+            C.conv_wgrad(xp, dc1, dwp, 2, 3, None, 1, 2)
+            C.stem_unpack_dw(dwp, dst.view(K, R, 7, 8), 3)
+
+        if tgt is not None and _side.active(dy):
+            _side.run(wgrad, (xp, dc1))
+        else:
+            wgrad()
+        if tgt is not None:
+            _sink.ready(conv.weight)
+        else:
+            grads[0] = dst
+        return (None, None, *grads)         # the image batch needs no gradient
+
+
+_STEM_PACKED = os.environ.get("DPA_NO_PACKED_STEM", "0") != "1"
+
+
+def can_fuse_stem_packed(stem, x: torch.Tensor) -> bool:
+    """``x``: the NCHW image batch.  3 channels, even width, the standard 7x7 / 2 / 3 stem convolution."""
+    conv = stem.conv1
+    return (_STEM_PACKED and STEM_FUSED and ENABLED and x.is_cuda and stem.training and torch.is_grad_enabled()
+            and conv.weight_lp is not None and not x.requires_grad and x.dim() == 4 and x.shape[1] == 3
+            and x.shape[3] % 2 == 0 and tuple(conv.weight_lp.shape[1:]) == (7, 7, 8) and conv.stride == 2 and conv.padding == 3)
+
+
+def stem_packed(stem_mod, x: torch.Tensor) -> torch.Tensor:
+    xp = _ext.load().nchw_to_pairs(x.contiguous())
+    return _StemPackedFn.apply(xp, stem_mod, stem_mod.conv1.weight, stem_mod.bn1.weight, stem_mod.bn1.bias)
+
+
 def can_fuse_stem(stem, x: torch.Tensor) -> bool:
     return (STEM_FUSED and ENABLED and x.is_cuda and stem.training and torch.is_grad_enabled()
             and stem.conv1.weight_lp is not None and not x.requires_grad)

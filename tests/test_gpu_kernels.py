@@ -681,6 +681,56 @@ def test_dropout_residual_bf16_and_gpt2_with_dropout():
     assert abs(float(e1) - float(e2)) < 1e-4 and abs(float(l1) - float(l2)) > 1e-4     # (loss rows are summed with float atomics)
 
 
+@pytest.mark.parametrize("N,H,W", [(4, 64, 64), (2, 50, 38), (3, 224, 224)])
+def test_pair_packed_stem_matches_the_channel_padded_stem(N, H, W):
+    """The stem on the pixel-pair layout (``nchw_to_pairs`` + 7 x 4-tap convolution with stride (2, 1) / padding (3, 2) +
+    packed weight gradient, ops/block.py ``_StemPackedFn``) against the same node on the 8-channel-padded image: output,
+    filter gradient (in the parameter's [K,7,7,8] layout; padded channels stay zero) and BatchNorm gradients.  Also the
+    layout kernels against their index definitions."""
+    from distributedpytorch_amd import ops
+    from distributedpytorch_amd.models import resnet
+    from distributedpytorch_amd.ops import block as _block
+    from distributedpytorch_amd.parallel.flat import FlatParams
+    C_ = _C()
+    torch.manual_seed(N + H)
+    x = torch.randn(N, 3, H, W, device=DEV)
+    xp = C_.nchw_to_pairs(x)
+    ref = torch.zeros(N, H, W // 2, 8, device=DEV)
+    ref[..., 0:3] = x[:, :, :, 0::2].permute(0, 2, 3, 1)
+    ref[..., 3:6] = x[:, :, :, 1::2].permute(0, 2, 3, 1)
+    assert torch.equal(xp, ref.to(torch.bfloat16))
+    stem = resnet.Stem().to(DEV).train()
+    flat = FlatParams(stem)
+    assert _block.can_fuse_stem_packed(stem, x)
+    w = stem.conv1.weight_lp                                             # [64, 7, 7, 8] bf16, channels 3.. zero
+    wp = C_.stem_pack_filter(w, 3)
+    for sp in range(4):
+        for half in range(2):
+            s_ = 2 * sp + half - 1
+            want = w[:, :, s_, :3] if s_ >= 0 else torch.zeros_like(w[:, :, 0, :3])
+            assert torch.equal(wp[:, :, sp, half * 3:half * 3 + 3], want)
+    assert float(wp[..., 6:].abs().max()) == 0.0
+
+    def run(packed):
+        flat.grad.zero_()
+        y = _block.stem_packed(stem, x) if packed else _block.stem(stem, ops.to_nhwc(x, 8))
+        g = torch.Generator(device=DEV).manual_seed(5)
+        dy = torch.randn(y.shape, generator=g, device=DEV).to(torch.bfloat16)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        return y.detach().float(), [p.grad.detach().clone() for p in (stem.conv1.weight, stem.bn1.weight, stem.bn1.bias)]
+
+    y0, g0 = run(False)
+    y1, g1 = run(True)
+    assert y1.shape == y0.shape
+    _close(y1, y0, 2e-2, 2e-2, "packed stem output", max_bad_frac=1e-3)
+    scale = float(g0[0].abs().max())
+    assert float((g1[0] - g0[0]).abs().max()) <= 2e-2 * scale, (float((g1[0] - g0[0]).abs().max()), scale)
+    assert float(g1[0][..., 3:].abs().max()) == 0.0
+    for a, b, name in ((g1[1], g0[1], "dgamma"), (g1[2], g0[2], "dbeta")):
+        assert float((a - b).abs().max()) <= 3e-2 * float(b.abs().max()) + 1e-3, name
+
+
 def test_bn_apply_with_affine_residual_matches_fp32_reference():
     """bn_apply(x, r, ..., res_scale, res_shift): relu(x*s + b + (r*rs + rb)) - the projection shortcut's BatchNorm folded
     into bn3's apply (ops/block.py fold_ds) - against the plain fp32 expression."""
