@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak run: N training steps of a benchmark workload on fixed synthetic data (the loss must fall and stay finite,
-device memory must stop growing after the first steps).    python scripts/soak.py [resnet50|gpt2] [steps]"""
+device memory must stop growing after the first steps).    python scripts/soak.py [resnet50|gpt2] [steps] [batch]"""
 import os
 import sys
 
@@ -12,17 +12,18 @@ from distributedpytorch_amd.parallel.dp import DataParallel
 
 name = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 dev = torch.device("cuda")
 torch.manual_seed(0)
 if name == "gpt2":
     from distributedpytorch_amd.models import gpt2
     m = gpt2.gpt2_small().to(dev).train()
-    x = torch.randint(0, 50257, (8, 1024), device=dev); y = torch.randint(0, 50257, (8, 1024), device=dev)
+    x = torch.randint(0, 50257, (batch or 8, 1024), device=dev); y = torch.randint(0, 50257, (batch or 8, 1024), device=dev)
     lr = 0.01
 else:
     from distributedpytorch_amd.models import resnet
     m = resnet.resnet50().to(dev).train()
-    x = torch.randn(64, 3, 224, 224, device=dev); y = torch.randint(0, 1000, (64,), device=dev)
+    x = torch.randn(batch or 64, 3, 224, 224, device=dev); y = torch.randint(0, 1000, (batch or 64,), device=dev)
     lr = 0.02
 dp = DataParallel(m)
 opt = FusedSGD(dp.flat, lr=lr, momentum=0.9, weight_decay=1e-4)
