@@ -408,6 +408,7 @@ bool conv_wgrad_fuses_bias(const WgradArgs& a) {
 }
 
 void conv_wgrad(const WgradArgs& a, hipStream_t st) {
+    if (conv_wgrad_halo_ok(a)) { conv_wgrad_halo(a, st); return; }     // 3 x 3 on 56- / 28-wide maps: conv_wgrad_halo.hip
     const bool lin = a.R == 1 && a.S == 1 && a.pad == 0 && a.stride == 1;
     const bool dma = use_dma(a);
     const bool bias = a.dbias != nullptr && conv_wgrad_fuses_bias(a);

@@ -74,6 +74,9 @@ struct WgradArgs {
     float* dbias;     // optional fp32 [K]: += column sums of dy (bias gradient), computed on the MFMA beside dw
 };
 void conv_wgrad(const WgradArgs& a, hipStream_t st);
+// halo-tiled 3 x 3 / stride 1 / pad 1 weight gradient (conv_wgrad_halo.hip); conv_wgrad routes eligible problems to it
+bool conv_wgrad_halo_ok(const WgradArgs& a);
+void conv_wgrad_halo(const WgradArgs& a, hipStream_t st);
 // true when conv_wgrad's kernel for this problem also produces a.dbias (else the caller runs colsum_bf16)
 bool conv_wgrad_fuses_bias(const WgradArgs& a);
 

@@ -141,6 +141,20 @@ def test_conv_wgrad_split_k_large():
     _close(dw.view(K, C), ref, 5e-3, 5e-2, "wgrad split-k")
 
 
+@pytest.mark.parametrize("case", [(3, 56, 56, 64, 64), (2, 56, 56, 128, 64), (1, 56, 56, 64, 192), (5, 2, 56, 64, 64)])
+def test_conv_wgrad_halo_tiled_3x3_on_56_wide_maps(case):
+    """csrc/conv_wgrad_halo.hip (conv_wgrad routes 3 x 3 / stride 1 / pad 1 problems on 56-wide maps with 64-channel
+    slabs to it): image borders, several slabs, fewer tiles than workgroups, accumulation INTO dw."""
+    N, H, W, C, K = case
+    x = _rand_bf16(N, H, W, C, seed=31)
+    dy = _rand_bf16(N, H, W, K, scale=0.1, seed=32)
+    dw = torch.full((K, 3, 3, C), 0.25, device=DEV)
+    _C().conv_wgrad(x, dy, dw, 1, 1)
+    ref = torch.nn.grad.conv2d_weight(x.float().cpu().permute(0, 3, 1, 2), (K, C, 3, 3), dy.float().cpu().permute(0, 3, 1, 2),
+                                      stride=1, padding=1).permute(0, 2, 3, 1) + 0.25
+    _close(dw, ref, 5e-3, 2e-2, "halo wgrad")
+
+
 @pytest.mark.parametrize("shape", [(4096, 768, 2304), (1000, 64, 64), (2048, 3072, 776), (8, 9, 9, 64, 128)])
 def test_conv_wgrad_bias_gradient(shape):
     """dbias += column sums of dy, from the wgrad kernel itself (Linear shapes: an MFMA against ones) or from the
