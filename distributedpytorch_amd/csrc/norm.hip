@@ -130,28 +130,44 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(float* __restrict__ st
     }
 }
 
-template <bool RELU, bool RES>
+// 8 per-channel coefficients of one 16-byte chunk
+__device__ __forceinline__ void load8(const float* __restrict__ p, int ch, float (&o)[8]) {
+    const float4 a = *(const float4*)(p + ch * 8), b = *(const float4*)(p + ch * 8 + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+
+// The grid-stride loop moves a thread by gridDim.x * 256 chunks; when the chunks per row (C / 8) divide 256 - every
+// power-of-two channel count up to 2048 - a thread stays on ONE channel group for the whole loop, so its coefficients
+// are loaded once (INV) instead of with every chunk: the loop body was 2-3 data loads next to 4-8 coefficient loads
+// (L1 hits, but vector-memory instructions all the same) and a 64-bit modulo.
+template <bool RELU, bool RES, bool INV>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ res,
                                                        unsigned short* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, unsigned char* __restrict__ mask,
                                                        long nchunks, int cpr, const float* __restrict__ rscale,
                                                        const float* __restrict__ rshift) {
+    constexpr bool inv = INV;
+    const bool rproj = RES && rscale != nullptr;   // the residual is itself a raw conv output behind its own BatchNorm (projection shortcut)
+    float sc[8], sh[8], rs[8], rb[8];
+    if (inv) {
+        const int ch = threadIdx.x % cpr;
+        load8(scale, ch, sc); load8(shift, ch, sh);
+        if (rproj) { load8(rscale, ch, rs); load8(rshift, ch, rb); }
+    }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long)gridDim.x * 256) {
-        const int ch = (int)(i % cpr);
         uint4 v = *(const uint4*)(x + i * 8);
+        uint4 rv;
+        if (RES) rv = *(const uint4*)(res + i * 8);
+        if (!inv) {
+            const int ch = (int)(i % cpr);
+            load8(scale, ch, sc); load8(shift, ch, sh);
+            if (rproj) { load8(rscale, ch, rs); load8(rshift, ch, rb); }
+        }
         float f[8]; unpack8(v, f);
-        const float4 s0 = *(const float4*)(scale + ch * 8), s1 = *(const float4*)(scale + ch * 8 + 4);
-        const float4 b0 = *(const float4*)(shift + ch * 8), b1 = *(const float4*)(shift + ch * 8 + 4);
-        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         float r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (RES) {
-            uint4 rv = *(const uint4*)(res + i * 8); unpack8(rv, r);
-            if (rscale != nullptr) {   // the residual is itself a raw conv output behind its own BatchNorm (projection shortcut)
-                const float4 q0 = *(const float4*)(rscale + ch * 8), q1 = *(const float4*)(rscale + ch * 8 + 4);
-                const float4 p0 = *(const float4*)(rshift + ch * 8), p1 = *(const float4*)(rshift + ch * 8 + 4);
-                const float rs[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-                const float rb[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+            unpack8(rv, r);
+            if (rproj) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) r[j] = r[j] * rs[j] + rb[j];
             }
@@ -226,24 +242,35 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
     }
 }
 
-template <bool RELU>
+template <bool RELU, bool INV>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* __restrict__ dy, const unsigned char* __restrict__ mask,
                                                            const unsigned short* __restrict__ x, const float* __restrict__ cA,
                                                            const float* __restrict__ cB, const float* __restrict__ cC,
                                                            unsigned short* __restrict__ dx, long nchunks, int cpr) {
+    constexpr bool inv = INV;                      // coefficients loaded once per thread (see bn_apply_kernel)
+    float a[8], b[8], c[8];
+    if (inv) {
+        const int ch = threadIdx.x % cpr;
+        load8(cA, ch, a); load8(cB, ch, b); load8(cC, ch, c);
+    }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long)gridDim.x * 256) {
-        const int ch = (int)(i % cpr);
+        const uint4 gv = *(const uint4*)(dy + i * 8);
+        const uint4 xv = *(const uint4*)(x + i * 8);
+        unsigned m = 0xffu;
+        if (RELU) m = mask[i];
+        if (!inv) {
+            const int ch = (int)(i % cpr);
+            load8(cA, ch, a); load8(cB, ch, b); load8(cC, ch, c);
+        }
         float g[8], xf[8];
-        { uint4 v = *(const uint4*)(dy + i * 8); unpack8(v, g); }
-        { uint4 v = *(const uint4*)(x + i * 8); unpack8(v, xf); }
+        unpack8(gv, g); unpack8(xv, xf);
         if (RELU) {
-            const unsigned m = mask[i];
 #pragma unroll
             for (int j = 0; j < 8; ++j) g[j] = ((m >> j) & 1u) ? g[j] : 0.f;
         }
         float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(cA[ch * 8 + j], g[j], __builtin_fmaf(cB[ch * 8 + j], xf[j], cC[ch * 8 + j]));   // same association as tail_bwd.hip
+        for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(a[j], g[j], __builtin_fmaf(b[j], xf[j], c[j]));   // same association as tail_bwd.hip
         *(uint4*)(dx + i * 8) = pack8(o);
     }
 }
@@ -440,6 +467,12 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const unsigned s
     }
 }
 
+// experiment switch: DPA_BN_INV=0 re-loads the per-channel coefficients with every chunk (the round-1 loops)
+inline bool bn_inv_enabled() {
+    static const bool v = [] { const char* e = getenv("DPA_BN_INV"); return !(e && atoi(e) == 0); }();
+    return v;
+}
+
 inline int stream_grid(long nchunks) {
     long b = (nchunks + 255) / 256;
     if (b > 4096) b = 4096;
@@ -473,13 +506,13 @@ void bn_apply(const void* x, const void* residual, void* y, const float* scale, 
     const int cpr = C / 8;
     dim3 g(stream_grid(nchunks)), b(256);
     auto X = (const unsigned short*)x; auto R = (const unsigned short*)residual; auto Y = (unsigned short*)y;
-    if (relu) {
-        if (R) hipLaunchKernelGGL((bn_apply_kernel<true, true>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift);
-        else   hipLaunchKernelGGL((bn_apply_kernel<true, false>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift);
-    } else {
-        if (R) hipLaunchKernelGGL((bn_apply_kernel<false, true>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift);
-        else   hipLaunchKernelGGL((bn_apply_kernel<false, false>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift);
-    }
+    const bool inv = 256 % cpr == 0 && bn_inv_enabled();   // a thread never leaves its channel group (see the kernel)
+#define DPA_BN_APPLY(RELU_, RES_)                                                                                     \
+    if (inv) hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, true>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift); \
+    else     hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, false>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift)
+    if (relu) { if (R) { DPA_BN_APPLY(true, true); } else { DPA_BN_APPLY(true, false); } }
+    else      { if (R) { DPA_BN_APPLY(false, true); } else { DPA_BN_APPLY(false, false); } }
+#undef DPA_BN_APPLY
 }
 
 void bn_bwd_stats(const void* dy, const unsigned char* mask, const void* x, const float* mean, const float* invstd,
@@ -505,8 +538,14 @@ void bn_bwd_apply(const void* dy, const unsigned char* mask, const void* x, cons
     dim3 g(stream_grid(nchunks)), b(256);
     auto DY = (const unsigned short*)dy; auto X = (const unsigned short*)x;
     auto DX = (unsigned short*)dx;
-    if (relu) hipLaunchKernelGGL((bn_bwd_apply_kernel<true>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr);
-    else      hipLaunchKernelGGL((bn_bwd_apply_kernel<false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr);
+    const bool inv = 256 % cpr == 0 && bn_inv_enabled();
+    if (relu) {
+        if (inv) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr);
+        else     hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr);
+    } else {
+        if (inv) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr);
+        else     hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr);
+    }
 }
 
 void relu_mask_mul(const void* dy, const unsigned char* mask, void* out, long n, hipStream_t st) {
