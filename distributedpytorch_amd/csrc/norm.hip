@@ -311,6 +311,14 @@ __global__ __launch_bounds__(256) void fold_rows_kernel(const float* __restrict_
     out[(long)blockIdx.y * cols + col] = s;
 }
 
+__device__ __forceinline__ uint4 ld16_rt(const unsigned short* p, int nt) {
+    if (nt) {
+        const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+        return uint4{v[0], v[1], v[2], v[3]};
+    }
+    return *(const uint4*)p;
+}
+
 // ------------------------------------------------------------------ stem: BatchNorm + ReLU + 3x3/2 max pool, fused
 // The stem's activation (N x 112 x 112 x 64 at batch 256: 411 MB) is the largest tensor of the network.  Unfused it
 // is written by bn_apply, read by the pool, and its gradient is written by the pool backward and read twice by the
@@ -406,7 +414,7 @@ __device__ __forceinline__ void pool_patch_gather(const unsigned short* __restri
 __global__ __launch_bounds__(256) void pool_bn_bwd_stats_kernel(const unsigned short* __restrict__ dp, const unsigned char* __restrict__ idx,
                                                                 const unsigned short* __restrict__ x, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, float* __restrict__ stats,
-                                                                long patches, int C, int H, int W, int Ho, int Wo, int rpb, int replicas) {
+                                                                long patches, int C, int H, int W, int Ho, int Wo, int rpb, int replicas, int nt) {
     const int cpr = C / 8;
     reduce_rows([&](long r, int ch, float (&s)[8], float (&q)[8]) {          // "row" = one 2 x 2 patch
         const unsigned pt = (unsigned)r;
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_stats_kernel(const unsigned s
         for (int p_ = 0; p_ < 4; ++p_) {
             const int hi = 2 * a + (p_ >> 1), wi = 2 * b + (p_ & 1);
             in[p_] = hi < H && wi < W;
-            xv[p_] = *(const uint4*)(x + (((size_t)n * H + min(hi, H - 1)) * W + min(wi, W - 1)) * C + ch * 8);
+            xv[p_] = ld16_rt(x + (((size_t)n * H + min(hi, H - 1)) * W + min(wi, W - 1)) * C + ch * 8, nt);
         }
         float g[4][8];
         pool_patch_gather(dp, idx, n, a, b, ch, Ho, Wo, cpr, g);
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const unsigned s
                                                                 const unsigned short* __restrict__ x, const float* __restrict__ cA,
                                                                 const float* __restrict__ cB, const float* __restrict__ cC,
                                                                 unsigned short* __restrict__ dx, int N, int H, int W, int C,
-                                                                int Ho, int Wo) {
+                                                                int Ho, int Wo, int nt) {
     const int cpr = C / 8;
     const unsigned total = (unsigned)N * Ho * Wo * cpr;                       // patches x channel chunks
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
@@ -458,7 +466,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const unsigned s
             const int hi = 2 * a + (p_ >> 1), wi = 2 * b + (p_ & 1);
             in[p_] = hi < H && wi < W;
             off[p_] = (((size_t)n * H + min(hi, H - 1)) * W + min(wi, W - 1)) * C + ch * 8;
-            xv[p_] = *(const uint4*)(x + off[p_]);
+            xv[p_] = ld16_rt(x + off[p_], nt);
         }
         float g[4][8];
         pool_patch_gather(dp, idx, n, a, b, ch, Ho, Wo, cpr, g);
@@ -590,14 +598,15 @@ void pool_bn_bwd_stats(const void* dp, const unsigned char* idx, const void* x, 
     const long P = (long)N * H * W, patches = (long)N * Ho * Wo;      // grid as for a P-row reduction (the callers size the
     const int grid = bn_stats_rows(P);                               // partial-row buffer by bn_stats_rows(P)); work = patches
     hipLaunchKernelGGL(pool_bn_bwd_stats_kernel, dim3(grid), dim3(256), 0, st, (const unsigned short*)dp, idx,
-                       (const unsigned short*)x, mean, invstd, stats, patches, C, H, W, Ho, Wo, (int)((patches + grid - 1) / grid), replicas);
+                       (const unsigned short*)x, mean, invstd, stats, patches, C, H, W, Ho, Wo, (int)((patches + grid - 1) / grid), replicas,
+                       (bn_nt_enabled() & 4) != 0);
 }
 
 void pool_bn_bwd_apply(const void* dp, const unsigned char* idx, const void* x, const float* coefA, const float* coefB,
                        const float* coefC, void* dx, int N, int H, int W, int C, int Ho, int Wo, hipStream_t st) {
     const long total = (long)N * Ho * Wo * (C / 8);
     hipLaunchKernelGGL(pool_bn_bwd_apply_kernel, dim3(stream_grid(total)), dim3(256), 0, st, (const unsigned short*)dp, idx,
-                       (const unsigned short*)x, coefA, coefB, coefC, (unsigned short*)dx, N, H, W, C, Ho, Wo);
+                       (const unsigned short*)x, coefA, coefB, coefC, (unsigned short*)dx, N, H, W, C, Ho, Wo, (bn_nt_enabled() & 4) != 0);
 }
 
 }  // namespace dpa
