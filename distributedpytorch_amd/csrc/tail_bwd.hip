@@ -58,7 +58,8 @@ __device__ __forceinline__ int d_off(int row, int ch) {
     return row * D_ROWB + ((ch & ~15) << 4) + (((ch & 15) ^ xor_key(row)) << 4);
 }
 
-template <bool STATS>
+// AUX: cache-policy bits of the operand loads (2 = nt: every operand here is streamed once; DPA_TAIL_NT)
+template <bool STATS, int AUX = 0>
 __global__ __launch_bounds__(256, 1) void tail_bwd_kernel(TailBwdArgs a, int steps_per_wg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
     unsigned char* const dimg = tsm;
@@ -119,16 +120,16 @@ __global__ __launch_bounds__(256, 1) void tail_bwd_kernel(TailBwdArgs a, int ste
     {                                                                                                       \
         _Pragma("unroll") for (int i = 4 * (H); i < 4 * (H) + 4; ++i) {                                     \
             const unsigned o = d_goff + (unsigned)(i * 8 * D_ROWB);                                         \
-            dreg[i] = __builtin_amdgcn_raw_buffer_load_b128(dors, o, 0, 0);                                 \
-            creg[i] = __builtin_amdgcn_raw_buffer_load_b128(crrs, o, 0, 0);                                 \
-            mreg[i] = a.kout ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(kors, o >> 4, 0, 0) : 0xffu;   \
+            dreg[i] = __builtin_amdgcn_raw_buffer_load_b128(dors, o, 0, AUX);                                 \
+            creg[i] = __builtin_amdgcn_raw_buffer_load_b128(crrs, o, 0, AUX);                                 \
+            mreg[i] = a.kout ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(kors, o >> 4, 0, AUX) : 0xffu;   \
         }                                                                                                   \
         {                                                                                                   \
             const unsigned o = x_goff + (unsigned)((H) * 32 * X_ROWB);                                      \
-            xreg[H] = __builtin_amdgcn_raw_buffer_load_b128(xirs, o, 0, 0);                                 \
+            xreg[H] = __builtin_amdgcn_raw_buffer_load_b128(xirs, o, 0, AUX);                                 \
             if (STATS) {                                                                                    \
-                sreg[H] = __builtin_amdgcn_raw_buffer_load_b128(sxrs, o, 0, 0);                             \
-                smr[H] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(smrs, o >> 4, 0, 0);                 \
+                sreg[H] = __builtin_amdgcn_raw_buffer_load_b128(sxrs, o, 0, AUX);                             \
+                smr[H] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(smrs, o >> 4, 0, AUX);                 \
             }                                                                                               \
         }                                                                                                   \
         if (H) { d_goff += (unsigned)(TB_R * D_ROWB); x_goff += (unsigned)(TB_R * X_ROWB); }                \
@@ -326,7 +327,7 @@ __device__ __forceinline__ int d2_off(int row, int ch) {
     return row * D2_ROWB + ((ch & ~15) << 4) + (((ch & 15) ^ xor_key(row)) << 4);
 }
 
-template <bool STATS>
+template <bool STATS, int AUX = 0>
 __global__ __launch_bounds__(T2_NT) void tail_bwd_kernel_128(TailBwdArgs a, int steps_per_wg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
     unsigned char* const dimg = tsm;
@@ -380,15 +381,15 @@ __global__ __launch_bounds__(T2_NT) void tail_bwd_kernel_128(TailBwdArgs a, int 
     {                                                                                                       \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                     \
             const unsigned o = d_goff + (unsigned)(i * 8 * D2_ROWB);                                        \
-            dreg[i] = __builtin_amdgcn_raw_buffer_load_b128(dors, o, 0, 0);                                 \
-            creg[i] = __builtin_amdgcn_raw_buffer_load_b128(crrs, o, 0, 0);                                 \
-            mreg[i] = a.kout ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(kors, o >> 4, 0, 0) : 0xffu;   \
+            dreg[i] = __builtin_amdgcn_raw_buffer_load_b128(dors, o, 0, AUX);                                 \
+            creg[i] = __builtin_amdgcn_raw_buffer_load_b128(crrs, o, 0, AUX);                                 \
+            mreg[i] = a.kout ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(kors, o >> 4, 0, AUX) : 0xffu;   \
         }                                                                                                   \
         if (xrole) {                                                                                        \
-            xreg = __builtin_amdgcn_raw_buffer_load_b128(xirs, x_goff, 0, 0);                               \
+            xreg = __builtin_amdgcn_raw_buffer_load_b128(xirs, x_goff, 0, AUX);                               \
             if (STATS) {                                                                                    \
-                sreg = __builtin_amdgcn_raw_buffer_load_b128(sxrs, x_goff, 0, 0);                           \
-                smr = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(smrs, x_goff >> 4, 0, 0);               \
+                sreg = __builtin_amdgcn_raw_buffer_load_b128(sxrs, x_goff, 0, AUX);                           \
+                smr = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(smrs, x_goff >> 4, 0, AUX);               \
             }                                                                                               \
         }                                                                                                   \
         d_goff += (unsigned)(T2_R * D2_ROWB); x_goff += (unsigned)(T2_R * X2_ROWB);                         \
@@ -581,6 +582,8 @@ void tail_bwd(const TailBwdArgs& a, hipStream_t st) {
     if (!prepared) {
         allow_lds(tail_bwd_kernel<true>, TB_LDS); allow_lds(tail_bwd_kernel<false>, TB_LDS);
         allow_lds(tail_bwd_kernel_128<true>, T2_LDS); allow_lds(tail_bwd_kernel_128<false>, T2_LDS);
+        allow_lds(tail_bwd_kernel<true, 2>, TB_LDS); allow_lds(tail_bwd_kernel<false, 2>, TB_LDS);
+        allow_lds(tail_bwd_kernel_128<true, 2>, T2_LDS); allow_lds(tail_bwd_kernel_128<false, 2>, T2_LDS);
         prepared = true;
     }
     // one workgroup per CU (83 / 158 KiB of LDS each): 254 us at 256 workgroups, 264 us at 512 on the stage-1 shape
@@ -591,17 +594,18 @@ void tail_bwd(const TailBwdArgs& a, hipStream_t st) {
     long grid = steps < target ? steps : target;
     const int spw = (int)((steps + grid - 1) / grid);
     grid = (steps + spw - 1) / spw;
-    if (wide) {
-        if (a.stats != nullptr)
-            hipLaunchKernelGGL(tail_bwd_kernel_128<true>, dim3((unsigned)grid), dim3(T2_NT), T2_LDS, st, a, spw);
-        else
-            hipLaunchKernelGGL(tail_bwd_kernel_128<false>, dim3((unsigned)grid), dim3(T2_NT), T2_LDS, st, a, spw);
-        return;
+    static const bool nt = [] { const char* e = getenv("DPA_TAIL_NT"); return !(e && atoi(e) == 0); }();   // +0.3 % (14,782 / 14,831 vs 14,848 / 14,869 img/s at batch 512)
+#define DPA_TAIL(KERNEL_, THREADS_, LDS_)                                                                        \
+    if (a.stats != nullptr) {                                                                                    \
+        if (nt) hipLaunchKernelGGL((KERNEL_<true, 2>), dim3((unsigned)grid), dim3(THREADS_), LDS_, st, a, spw);   \
+        else    hipLaunchKernelGGL((KERNEL_<true, 0>), dim3((unsigned)grid), dim3(THREADS_), LDS_, st, a, spw);   \
+    } else {                                                                                                     \
+        if (nt) hipLaunchKernelGGL((KERNEL_<false, 2>), dim3((unsigned)grid), dim3(THREADS_), LDS_, st, a, spw);  \
+        else    hipLaunchKernelGGL((KERNEL_<false, 0>), dim3((unsigned)grid), dim3(THREADS_), LDS_, st, a, spw);  \
     }
-    if (a.stats != nullptr)
-        hipLaunchKernelGGL(tail_bwd_kernel<true>, dim3((unsigned)grid), dim3(256), TB_LDS, st, a, spw);
-    else
-        hipLaunchKernelGGL(tail_bwd_kernel<false>, dim3((unsigned)grid), dim3(256), TB_LDS, st, a, spw);
+    if (wide) { DPA_TAIL(tail_bwd_kernel_128, T2_NT, T2_LDS) }
+    else      { DPA_TAIL(tail_bwd_kernel, 256, TB_LDS) }
+#undef DPA_TAIL
 }
 
 }  // namespace dpa
