@@ -157,12 +157,13 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------ elementwise
-template <int OP>  // 0 add, 1 add+relu, 2 relu_bwd(a=dy, b=y), 3 gelu_fwd(a), 4 gelu_bwd(a=dy, b=x)
+template <int OP, bool NT = false>  // 0 add, 1 add+relu, 2 relu_bwd(a=dy, b=y), 3 gelu_fwd(a), 4 gelu_bwd(a=dy, b=x)
 __global__ __launch_bounds__(256) void ew_kernel(const unsigned short* __restrict__ a, const unsigned short* __restrict__ b,
                                                  unsigned short* __restrict__ y, long nchunks) {
     GRID_STRIDE(i, nchunks) {
         float fa[8], fb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        { uint4 v = *(const uint4*)(a + i * 8); unpack8(v, fa); }
+        if (NT) { const u32x4 w = __builtin_nontemporal_load((const u32x4*)(a + i * 8)); uint4 v{w[0], w[1], w[2], w[3]}; unpack8(v, fa); }
+        else { uint4 v = *(const uint4*)(a + i * 8); unpack8(v, fa); }
         if (OP != 3) { uint4 v = *(const uint4*)(b + i * 8); unpack8(v, fb); }
         float o[8];
 #pragma unroll
@@ -193,7 +194,11 @@ __global__ void ew_tail_kernel(const unsigned short* a, const unsigned short* b,
 template <int OP>
 void launch_ew(const void* a, const void* b, void* y, long n, hipStream_t st) {
     const long nchunks = n / 8;
-    if (nchunks > 0)
+    static const bool nt = [] { const char* e = getenv("DPA_LN_NT"); return !(e && atoi(e) == 0); }();   // the GELU input is read again in backward only (see layernorm_bwd)
+    if (nchunks > 0 && OP == 3 && nt)
+        hipLaunchKernelGGL((ew_kernel<OP, true>), dim3(grid_for(nchunks)), dim3(256), 0, st, (const unsigned short*)a,
+                           (const unsigned short*)b, (unsigned short*)y, nchunks);
+    else if (nchunks > 0)
         hipLaunchKernelGGL((ew_kernel<OP>), dim3(grid_for(nchunks)), dim3(256), 0, st, (const unsigned short*)a,
                            (const unsigned short*)b, (unsigned short*)y, nchunks);
     if (n % 8)

@@ -55,7 +55,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const unsigned short
 // chain load -> two wave reductions -> store, i.e. one memory round trip per row per wave: with 4 waves on a CU and
 // no prefetch it ran at 42 us for 8192 x 768 (HBM time: 10 us).  Eight waves per workgroup and the NEXT row's loads
 // issued before the current row is reduced keep four times as many rows in flight without adding partial rows to fold.
-template <int NCH, int LN_BWD_WAVES>
+template <bool NT>
+__device__ __forceinline__ uint4 ln_ld16(const unsigned short* p) {
+    if (NT) {
+        const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+        return uint4{v[0], v[1], v[2], v[3]};
+    }
+    return *(const uint4*)p;
+}
+
+template <int NCH, int LN_BWD_WAVES, bool NT = false>
 __global__ __launch_bounds__(LN_BWD_WAVES * 64) void layernorm_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
                                                             const float* __restrict__ g, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, unsigned short* __restrict__ dx,
@@ -78,9 +87,9 @@ __global__ __launch_bounds__(LN_BWD_WAVES * 64) void layernorm_bwd_kernel(const 
         _Pragma("unroll") for (int k = 0; k < NCH; ++k) {                                       \
             const int ch = lane + k * 64;                                                       \
             if (ch < nch) {                                                                     \
-                ndy[k] = *(const uint4*)(dy + (R) * C + ch * 8);                                \
-                nx[k] = *(const uint4*)(x + (R) * C + ch * 8);                                  \
-                if (addend != nullptr) nad[k] = *(const uint4*)(addend + (R) * C + ch * 8);     \
+                ndy[k] = ln_ld16<NT>(dy + (R) * C + ch * 8);                                    \
+                nx[k] = ln_ld16<NT>(x + (R) * C + ch * 8);                                      \
+                if (addend != nullptr) nad[k] = ln_ld16<NT>(addend + (R) * C + ch * 8);         \
             }                                                                                   \
         }                                                                                       \
     }
@@ -289,10 +298,11 @@ void layernorm_fwd(const void* x, const float* g, const float* b, void* y, float
 void layernorm_bwd(const void* dy, const void* x, const float* g, const float* mean, const float* rstd,
                    void* dx, float* dg_partial, float* db_partial, int partial_rows, long rows, int C, const void* addend,
                    hipStream_t st) {
-#define DPA_LN_BWD_H(NCH_, W_) hipLaunchKernelGGL((layernorm_bwd_kernel<NCH_, W_>), dim3(partial_rows), dim3(W_ * 64), 0, st, \
+    static const bool nt = [] { const char* e = getenv("DPA_LN_NT"); return !(e && atoi(e) == 0); }();   // last use of x / dy / addend: GPT-2 +0.6 % together with the GELU input (757.1 / 759.5 vs 763.6 / 762.7k tok/s)
+#define DPA_LN_BWD_H(NCH_, W_, NT_) hipLaunchKernelGGL((layernorm_bwd_kernel<NCH_, W_, NT_>), dim3(partial_rows), dim3(W_ * 64), 0, st, \
         (const unsigned short*)dy, (const unsigned short*)x, g, mean, rstd, (unsigned short*)dx, dg_partial, db_partial, rows, C, \
         (const unsigned short*)addend)
-#define DPA_LN_BWD(NCH_) DPA_LN_BWD_H(NCH_, 8)
+#define DPA_LN_BWD(NCH_) if (nt) DPA_LN_BWD_H(NCH_, 8, true); else DPA_LN_BWD_H(NCH_, 8, false)
     if (C <= 512) DPA_LN_BWD(1); else if (C <= 1024) DPA_LN_BWD(2); else DPA_LN_BWD(4);
 #undef DPA_LN_BWD
 #undef DPA_LN_BWD_H
