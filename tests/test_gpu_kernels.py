@@ -189,7 +189,8 @@ def test_colsum():
     _close(out, x.float().sum(0), 1e-3, 1e-2, "colsum wide")
 
 
-@pytest.mark.parametrize("shape", [(4, 7, 7, 64), (2, 13, 11, 256), (3, 5, 5, 2048), (64, 28, 28, 128)])
+@pytest.mark.parametrize("shape", [(4, 7, 7, 64), (2, 13, 11, 256), (3, 5, 5, 2048), (64, 28, 28, 128),
+                                   (5, 9, 9, 48), (70, 15, 15, 136)])   # C / 8 = 6, 17: the apply kernels' per-chunk coefficient path
 @pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
 def test_batchnorm_fwd_bwd(shape, relu, res):
     from distributedpytorch_amd import ops
