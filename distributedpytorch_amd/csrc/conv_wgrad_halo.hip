@@ -16,6 +16,7 @@
 //   every read address is a per-lane constant (the XOR key depends on bit 1 of the slot, which a k-step of 16 and a
 //   second read 4 slots on leave alone) plus an immediate.
 //   LDS: three stage buffers, the DMAs of tiles t + 1 and t + 2 in flight under the MFMAs of tile t, one barrier per tile.
+#include <stdio.h>
 #include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
@@ -203,7 +204,11 @@ void launch_halo(const WgradArgs& a, hipStream_t st) {
     auto kernel = wgrad3x3_halo_kernel<W, TR>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        const hipError_t err = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (err != hipSuccess) {      // a launch without the attribute would fail silently and leave dw untouched
+            fprintf(stderr, "conv_wgrad_halo: cannot allow %d bytes of LDS: %s\n", Cfg::LDS_BYTES, hipGetErrorString(err));
+            abort();
+        }
         attr_set = true;
     }
     hipLaunchKernelGGL(kernel, dim3(slabs * wg_per_slab), dim3(512), Cfg::LDS_BYTES, st, a, slabs_c, wg_per_slab, tiles_total);
