@@ -154,16 +154,37 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
                                                        unsigned short* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, unsigned char* __restrict__ mask,
                                                        long nchunks, int cpr, const float* __restrict__ rscale,
-                                                       const float* __restrict__ rshift) {
+                                                       const float* __restrict__ rshift, int rev) {
     constexpr bool inv = INV;
     const bool rproj = RES && rscale != nullptr;   // the residual is itself a raw conv output behind its own BatchNorm (projection shortcut)
+    // rev (INV only; host: gridDim.x % 8 == 0, nchunks % 2048 == 0): walk the tensor the way the producing convolution
+    // left it in the caches and the way the consuming one will want it - the conv kernels give each XCD (workgroup id
+    // mod 8) one contiguous eighth of the pixel tiles, ascending, so the most recently written bytes are the ENDS of the
+    // eight ranges; this kernel's workgroup b takes eighth b & 7 and walks it DESCENDING, and so finishes at the heads
+    // of the ranges, where the next convolution starts.
+    long i0, step, count;
+    int ch0;
+    if (inv && rev) {
+        const long R = nchunks >> 3, GB = (long)(gridDim.x >> 3) * 256;
+        const long off0 = (long)(blockIdx.x >> 3) * 256 + threadIdx.x;
+        i0 = (long)((blockIdx.x & 7) + 1) * R - 1 - off0;
+        step = -GB;
+        count = off0 < R ? (R - off0 + GB - 1) / GB : 0;
+        ch0 = cpr - 1 - (int)(threadIdx.x % cpr);
+    } else {
+        const long S = (long)gridDim.x * 256;
+        i0 = (long)blockIdx.x * 256 + threadIdx.x;
+        step = S;
+        count = i0 < nchunks ? (nchunks - i0 + S - 1) / S : 0;
+        ch0 = threadIdx.x % cpr;
+    }
     float sc[8], sh[8], rs[8], rb[8];
     if (inv) {
-        const int ch = threadIdx.x % cpr;
-        load8(scale, ch, sc); load8(shift, ch, sh);
-        if (rproj) { load8(rscale, ch, rs); load8(rshift, ch, rb); }
+        load8(scale, ch0, sc); load8(shift, ch0, sh);
+        if (rproj) { load8(rscale, ch0, rs); load8(rshift, ch0, rb); }
     }
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long)gridDim.x * 256) {
+    long i = i0;
+    for (long it = 0; it < count; ++it, i += step) {
         uint4 v = ld16<NT>(x + i * 8);          // NT: the raw conv output is not read again before backward
         uint4 rv;
         if (RES) rv = ld16<NTR>(res + i * 8);
@@ -255,14 +276,28 @@ template <bool RELU, bool INV, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* __restrict__ dy, const unsigned char* __restrict__ mask,
                                                            const unsigned short* __restrict__ x, const float* __restrict__ cA,
                                                            const float* __restrict__ cB, const float* __restrict__ cC,
-                                                           unsigned short* __restrict__ dx, long nchunks, int cpr) {
+                                                           unsigned short* __restrict__ dx, long nchunks, int cpr, int rev) {
     constexpr bool inv = INV;                      // coefficients loaded once per thread (see bn_apply_kernel)
-    float a[8], b[8], c[8];
-    if (inv) {
-        const int ch = threadIdx.x % cpr;
-        load8(cA, ch, a); load8(cB, ch, b); load8(cC, ch, c);
+    long i0, step, count;                          // rev: each XCD's eighth of the tensor, descending (see bn_apply_kernel)
+    int ch0;
+    if (inv && rev) {
+        const long R = nchunks >> 3, GB = (long)(gridDim.x >> 3) * 256;
+        const long off0 = (long)(blockIdx.x >> 3) * 256 + threadIdx.x;
+        i0 = (long)((blockIdx.x & 7) + 1) * R - 1 - off0;
+        step = -GB;
+        count = off0 < R ? (R - off0 + GB - 1) / GB : 0;
+        ch0 = cpr - 1 - (int)(threadIdx.x % cpr);
+    } else {
+        const long S = (long)gridDim.x * 256;
+        i0 = (long)blockIdx.x * 256 + threadIdx.x;
+        step = S;
+        count = i0 < nchunks ? (nchunks - i0 + S - 1) / S : 0;
+        ch0 = threadIdx.x % cpr;
     }
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long)gridDim.x * 256) {
+    float a[8], b[8], c[8];
+    if (inv) { load8(cA, ch0, a); load8(cB, ch0, b); load8(cC, ch0, c); }
+    long i = i0;
+    for (long it = 0; it < count; ++it, i += step) {
         const uint4 gv = ld16<NT>(dy + i * 8);   // NT: last use of both operands
         const uint4 xv = ld16<NT>(x + i * 8);
         unsigned m = 0xffu;
@@ -499,6 +534,12 @@ inline int bn_nt_enabled() {
     return v;
 }
 
+// DPA_BN_REV (bit mask): reverse, XCD-partitioned traversal in bn_apply (bit 0) and bn_bwd_apply (bit 1)
+inline int bn_rev_enabled() {
+    static const int v = [] { const char* e = getenv("DPA_BN_REV"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 inline int stream_grid(long nchunks) {
     long b = (nchunks + 255) / 256;
     if (b > 4096) b = 4096;
@@ -534,11 +575,12 @@ void bn_apply(const void* x, const void* residual, void* y, const float* scale, 
     auto X = (const unsigned short*)x; auto R = (const unsigned short*)residual; auto Y = (unsigned short*)y;
     const bool inv = 256 % cpr == 0 && bn_inv_enabled();   // a thread never leaves its channel group (see the kernel)
     const bool nt = bn_nt_enabled() & 1, ntr = (bn_nt_enabled() & 2) != 0;
+    const int rev = ((bn_rev_enabled() & 1) && inv && g.x % 8 == 0 && nchunks % 2048 == 0) ? 1 : 0;
 #define DPA_BN_APPLY(RELU_, RES_)                                                                                     \
-    if (inv && nt && ntr) hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, true, true, true>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift); \
-    else if (inv && nt) hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, true, true>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift); \
-    else if (inv)  hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, true, false>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift); \
-    else           hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, false, false>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift)
+    if (inv && nt && ntr) hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, true, true, true>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift, rev); \
+    else if (inv && nt) hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, true, true>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift, rev); \
+    else if (inv)  hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, true, false>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift, rev); \
+    else           hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, false, false>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift, rev)
     if (relu) { if (R) { DPA_BN_APPLY(true, true); } else { DPA_BN_APPLY(true, false); } }
     else      { if (R) { DPA_BN_APPLY(false, true); } else { DPA_BN_APPLY(false, false); } }
 #undef DPA_BN_APPLY
@@ -569,14 +611,15 @@ void bn_bwd_apply(const void* dy, const unsigned char* mask, const void* x, cons
     auto DX = (unsigned short*)dx;
     const bool inv = 256 % cpr == 0 && bn_inv_enabled();
     const bool nt = bn_nt_enabled() & 1;
+    const int rev = (bn_rev_enabled() & 2) && inv && g.x % 8 == 0 && nchunks % 2048 == 0 ? 1 : 0;
     if (relu) {
-        if (inv && nt) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true, true>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr);
-        else if (inv)  hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr);
-        else           hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr);
+        if (inv && nt) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true, true>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev);
+        else if (inv)  hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev);
+        else           hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev);
     } else {
-        if (inv && nt) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true, true>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr);
-        else if (inv)  hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr);
-        else           hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr);
+        if (inv && nt) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true, true>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev);
+        else if (inv)  hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev);
+        else           hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev);
     }
 }
 
