@@ -108,6 +108,19 @@ def load_baseline_own(model: str, per_gpu_batch: int):
     return None
 
 
+def _rccl_version():
+    """RCCL's own version number (ncclGetVersion through the extension; torch's record as a fallback)."""
+    try:
+        from distributedpytorch_amd.ops import _ext
+        return int(_ext.load().RcclComm.version())
+    except Exception:  # noqa: BLE001
+        try:
+            v = torch.cuda.nccl.version()
+            return int(v[0]) * 10000 + int(v[1]) * 100 + int(v[2])
+        except Exception:  # noqa: BLE001
+            return None
+
+
 def main():
     args = parse()
     # collective-layer choices must be in the environment before distributedpytorch_amd.comm is imported
@@ -258,6 +271,13 @@ def main():
         elapsed = communicator.all_reduce_scalar(elapsed, "max")
         layer = "native (csrc/rccl_comm.cpp)" if communicator.native is not None else \
             ("c10d" if torch.distributed.is_initialized() else "none (single process, no collectives)")
+        no_comm = communicator.native is None and not torch.distributed.is_initialized()
+        if no_comm:
+            algo = None               # nothing is reduced: no algorithm to name
+        elif communicator.native is not None and communicator._direct:
+            algo = "direct/" + communicator.grad_wire
+        else:
+            algo = "ring"
         result = {"elapsed": elapsed, "items_per_rank_step": items, "loss": float(loss.detach().float().cpu()),
                   "flops_per_item": flops_item,
                   "allreduce_bytes_per_step": dp.stats["allreduce_bytes"] // max(1, args.steps),
@@ -265,7 +285,8 @@ def main():
                   "breakdown_ms": ({k: round(v, 3) for k, v in timer.summary().items()} if args.breakdown else None),
                   "config": dict(cfg, parallelism=f"dp{world}", per_gpu_batch=batch,
                                  buckets=len(dp.buckets), optimizer=f"fused SGD momentum {momentum}", comm_layer=layer,
-                                 allreduce=("direct/" + communicator.grad_wire) if (communicator.native is not None and communicator._direct) else "ring")}
+                                 allreduce=algo, gpu_max_hw_queues=int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                                 rccl_version=_rccl_version())}
 
     if rank == 0:
         elapsed = result["elapsed"]

@@ -109,6 +109,56 @@ def import_state_dict(module: nn.Module, sd: Dict[str, torch.Tensor], strict: bo
     return missing, unexpected
 
 
+def _dropout_state(module: nn.Module) -> dict:
+    """Positions of the counter-based dropout streams under ``module``: the MNIST nets' ``_DropState`` (one step
+    counter, host- or device-resident) and GPT-2's ``_DropSites`` (a call counter per module - a pipeline stage that is
+    one bare layer, e.g. the ``Embedding``, exposes one of these as ``module._drop`` too)."""
+    out: dict = {}
+    calls = {}
+    for name, mod in module.named_modules():
+        drop = getattr(mod, "_drop", None)
+        if drop is None:
+            continue
+        if hasattr(drop, "dev_step") and hasattr(drop, "step"):
+            if mod is module:
+                out["dropout_step"] = int(drop.dev_step.item()) if drop.dev_step is not None else int(drop.step)
+        elif hasattr(drop, "calls"):
+            calls[name] = int(drop.calls)
+    if calls:
+        key_map = getattr(module, "_dpa_key_map", None)
+        out["dropout_calls"] = calls if not key_map else {_model_level_module(name, key_map): v for name, v in calls.items()}
+    return out
+
+
+def _model_level_module(name: str, key_map: Dict[str, str]) -> str:
+    """Model-level name of a stage-local sub-module, through any state_dict entry that lives under it."""
+    prefix = name + "." if name else ""
+    for local, glob in key_map.items():
+        if local.startswith(prefix):
+            tail = local[len(prefix):]
+            if glob.endswith(tail):
+                return glob[: len(glob) - len(tail)].rstrip(".")
+    return name
+
+
+def _restore_dropout_state(module: nn.Module, payload: dict) -> None:
+    drop = getattr(module, "_drop", None)
+    if drop is not None and hasattr(drop, "dev_step") and "dropout_step" in payload:
+        drop.step = int(payload["dropout_step"])
+        if drop.dev_step is not None:
+            drop.dev_step.fill_(int(payload["dropout_step"]))
+    calls = payload.get("dropout_calls")
+    if calls:
+        key_map = getattr(module, "_dpa_key_map", None)
+        for name, mod in module.named_modules():
+            d = getattr(mod, "_drop", None)
+            if d is None or not hasattr(d, "calls") or hasattr(d, "dev_step"):
+                continue
+            key = _model_level_module(name, key_map) if key_map else name
+            if key in calls:
+                d.calls = int(calls[key])
+
+
 def save_checkpoint(path: str, module: nn.Module, optimizer=None, epoch: int = 0, extra: Optional[dict] = None,
                     comm=None, pipeline_comm=None, flat=None) -> Optional[str]:
     """Write ``{"model": state_dict, "optimizer": ..., "epoch": ...}`` with ``torch.save``.
@@ -121,13 +171,17 @@ def save_checkpoint(path: str, module: nn.Module, optimizer=None, epoch: int = 0
     opt_sd = optimizer.state_dict() if optimizer is not None and hasattr(optimizer, "state_dict") else None
     writer = True
     if pipeline_comm is not None and pipeline_comm.world_size > 1:
-        shards = pipeline_comm.gather_object((sd, opt_sd), dst=0)
+        shards = pipeline_comm.gather_object((sd, opt_sd, _dropout_state(module)), dst=0)
         if pipeline_comm.rank == 0:
             merged: "OrderedDict[str, torch.Tensor]" = OrderedDict()
-            for shard, _ in shards:
+            stage_drop: dict = {}
+            for shard, _, dstate in shards:
                 merged.update(shard)      # export_state_dict already names every entry by its model-level key
+                stage_drop.setdefault("dropout_calls", {}).update(dstate.get("dropout_calls", {}))
+                if "dropout_step" in dstate:
+                    stage_drop["dropout_step"] = dstate["dropout_step"]
             sd = merged
-            opt_sd = [o for _, o in shards]
+            opt_sd = [o for _, o, _ in shards]
         else:
             writer = False
     if comm is not None and comm.world_size > 1 and comm.rank != 0:
@@ -138,14 +192,21 @@ def save_checkpoint(path: str, module: nn.Module, optimizer=None, epoch: int = 0
     payload = {"model": sd, "optimizer": opt_sd, "epoch": epoch, "format": "torch-state_dict-v1"}
     if extra:
         payload["extra"] = extra
-    drop = getattr(module, "_drop", None)       # counter-based dropout stream of the MNIST nets: resume draws the NEXT masks
-    if drop is not None:
-        payload["dropout_step"] = int(drop.dev_step.item()) if drop.dev_step is not None else int(drop.step)
+    # counter-based dropout streams: resume draws the NEXT masks (pipeline: every stage's, gathered above)
+    dstate = stage_drop if (pipeline_comm is not None and pipeline_comm.world_size > 1) else _dropout_state(module)
+    payload.update({k: v for k, v in dstate.items() if v not in ({}, None)})
     tmp = path + ".tmp"
     torch.save(payload, tmp)
     os.replace(tmp, path)
     torch.save(sd, path + ".model")
     return path
+
+
+def peek_extra(path: str) -> dict:
+    """The ``extra`` record of a checkpoint (e.g. the pipeline's stage bounds) without touching any module."""
+    payload = torch.load(path, map_location="cpu", weights_only=True)
+    ex = payload.get("extra") if isinstance(payload, dict) else None
+    return dict(ex) if isinstance(ex, dict) else {}
 
 
 def load_checkpoint(path: str, module: nn.Module, optimizer=None, strict: bool = True, flat=None,
@@ -166,9 +227,6 @@ def load_checkpoint(path: str, module: nn.Module, optimizer=None, strict: bool =
             optimizer.load_state_dict(o)
     if flat is not None:
         flat.refresh_lp()
-    drop = getattr(module, "_drop", None)
-    if drop is not None and isinstance(payload, dict) and "dropout_step" in payload:
-        drop.step = int(payload["dropout_step"])
-        if drop.dev_step is not None:
-            drop.dev_step.fill_(int(payload["dropout_step"]))
+    if isinstance(payload, dict):
+        _restore_dropout_state(module, payload)
     return payload if isinstance(payload, dict) else {"model": sd}

@@ -34,6 +34,13 @@ _GLOO_NATIVE_DEVICE = os.environ.get("DPA_GLOO_DEVICE", "staged").lower() == "na
 # bucket-sized all-reduce with a host watchdog, result verified); if any rank fails it, EVERY rank falls back to c10d.
 _COMM_LAYER = os.environ.get("DPA_COMM", "native").lower()
 _SELFTEST_TIMEOUT_S = float(os.environ.get("DPA_COMM_SELFTEST_TIMEOUT", "60"))
+# With the native layer, torch.distributed is only the CONTROL PLANE (rendezvous, object broadcast, flag agreement, host
+# barriers) and runs on gloo: RCCL is then initialised exactly once per process, by csrc/rccl_comm.cpp (c10d's own
+# ProcessGroupNCCL would be a second world communicator: double channel buffers and proxy threads for one flag
+# all-reduce).  DPA_CONTROL_PLANE=nccl restores the round-2 arrangement (c10d on RCCL beside the native communicator).
+_CONTROL_PLANE = os.environ.get("DPA_CONTROL_PLANE", "gloo").lower()
+# blocking native send() / recv(): host watchdog (seconds) instead of a silent hang on an unmatched transfer
+_P2P_TIMEOUT_S = float(os.environ.get("DPA_P2P_TIMEOUT", "120"))
 
 
 def set_sync_debug(flag: bool) -> None:
@@ -81,7 +88,11 @@ def init_process_group(backend: str = "auto", init_method: Optional[str] = None,
     be = resolve_backend(backend, device)
     if be == "nccl":
         rccl_env_defaults()
-    kwargs = dict(backend=be, timeout=datetime.timedelta(seconds=timeout_s))
+    on_gpu = device is not None and device.type == "cuda"
+    native_wanted = _COMM_LAYER == "native" and be == "nccl" and on_gpu
+    # native layer: c10d is the control plane only, on gloo - ONE RCCL world communicator per process (the native one)
+    c10d_be = "gloo" if (native_wanted and _CONTROL_PLANE == "gloo") else be
+    kwargs = dict(backend=c10d_be, timeout=datetime.timedelta(seconds=timeout_s))
     if init_method is not None and init_method != "env://":
         kwargs.update(init_method=init_method, rank=rank, world_size=world_size)
         # keep env in step so libraries that read it agree (MP.py:175-176 does the same)
@@ -95,14 +106,19 @@ def init_process_group(backend: str = "auto", init_method: Optional[str] = None,
             os.environ.setdefault("RANK", str(rank))
         if world_size is not None:
             os.environ.setdefault("WORLD_SIZE", str(world_size))
-    if be == "nccl" and device is not None and device.type == "cuda":
+    if c10d_be == "nccl" and on_gpu:
         kwargs["device_id"] = device
     if not dist.is_initialized():
         dist.init_process_group(**kwargs)
     comm = Communicator(group=None, device=device)
-    if _COMM_LAYER == "native" and be == "nccl" and device is not None and device.type == "cuda" and \
-            (comm.world_size > 1 or _FORCE_COLLECTIVES):
+    comm._timeout_s = timeout_s
+    if native_wanted and (comm.world_size > 1 or _FORCE_COLLECTIVES):
         comm.attach_native()
+    if native_wanted and comm.native is None and comm._c10d_backend() != "nccl" and \
+            (comm.world_size > 1 or _FORCE_COLLECTIVES):
+        # the native layer is not there (never created, or it failed its self-test on some rank): device traffic
+        # goes through c10d's ProcessGroupNCCL after all - created now, collectively, and only now
+        comm._adopt_c10d_nccl()
     return comm
 
 
@@ -204,6 +220,8 @@ class Communicator:
         self.grad_wire = os.environ.get("DPA_GRAD_WIRE", "fp32").lower()
         self._scratch = {}
         self._obj_seq = 0
+        self._timeout_s = 300.0
+        self._c10d_sub_backend = None         # backend argument of dist.new_group for sub-groups (None = the default group's)
 
     # ---- native RCCL communicator: own comm stream, event hand-offs, direct / bf16-wire all-reduce ----
     def attach_native(self, parent: Optional["Communicator"] = None, member: bool = True) -> None:
@@ -236,28 +254,104 @@ class Communicator:
             self.native = None
         self._selftest_native(strict=False)
 
-    def _selftest_native(self, strict: bool) -> None:
-        """First contact of the native layer with the machine: a 4 KB and a 32 MB all-reduce of known values under a
-        host watchdog.  ``strict``: raise on failure (no c10d to fall back to); else every rank drops to c10d when
-        ANY rank failed (decided by a c10d all-reduce, so the ranks cannot disagree)."""
+    def _watch(self, ticket: int, what: str) -> None:
+        """Host watchdog around one native operation of the self-test / of a blocking point-to-point call."""
         import time
+        limit = _SELFTEST_TIMEOUT_S
+        t0 = time.monotonic()
+        while not self.native.query(ticket):
+            if time.monotonic() - t0 > limit:
+                raise TimeoutError(f"native {what} did not complete in {limit:.0f} s")
+            time.sleep(0.0005)
+        self.native.wait(ticket)
+
+    def _selftest_native(self, strict: bool) -> None:
+        """First contact of the native layer with the machine, every operation under a host watchdog and checked
+        against known values: a 4 KB and a 32 MB all-reduce; at world size > 1 also broadcast, reduce, reduce-scatter /
+        all-gather, a neighbour RING EXCHANGE through ``batch_p2p`` (ncclSend + ncclRecv in one group: what the
+        pipeline engine issues at every stage boundary) and an ``ncclCommSplit`` into two halves with an all-reduce
+        inside each.  ``strict``: raise on failure (no c10d to fall back to); else every rank drops to c10d when ANY
+        rank failed (decided by an all-reduce on the control plane, so the ranks cannot disagree)."""
         ok, why = True, ""
+        W, r = self.world_size, self.rank
         try:
             if self.native is None:
                 raise RuntimeError("no native communicator on this rank")
+            if _SELFTEST_TIMEOUT_S <= 0:
+                raise TimeoutError("self-test disabled by DPA_COMM_SELFTEST_TIMEOUT=0 (fallback rehearsal)")
+            dev = self.device
             for n in (1024, 8 * 2 ** 20):
-                t = torch.full((n,), float(self.rank + 1), dtype=torch.float32, device=self.device)
-                ticket = self.native.all_reduce(t, 0)
-                t0 = time.monotonic()
-                while not self.native.query(ticket):
-                    if time.monotonic() - t0 > _SELFTEST_TIMEOUT_S:
-                        raise TimeoutError(f"native all-reduce of {n} floats did not complete in {_SELFTEST_TIMEOUT_S:.0f} s")
-                    time.sleep(0.0005)
-                self.native.wait(ticket)
-                want = self.world_size * (self.world_size + 1) / 2.0
+                t = torch.full((n,), float(r + 1), dtype=torch.float32, device=dev)
+                self._watch(self.native.all_reduce(t, 0), f"all-reduce of {n} floats")
+                want = W * (W + 1) / 2.0
                 got = t[:: max(1, n // 64)].float().cpu()
                 if not bool((got == want).all()):
                     raise RuntimeError(f"native all-reduce returned {float(got[0])}, expected {want}")
+            if W > 1:
+                n = 4096
+                t = torch.full((n,), float(r + 1), dtype=torch.float32, device=dev)
+                self._watch(self.native.broadcast(t, W - 1), "broadcast")
+                if float(t[-1]) != float(W):
+                    raise RuntimeError(f"native broadcast returned {float(t[-1])}, expected {float(W)}")
+                t.fill_(float(r + 1))
+                self._watch(self.native.reduce(t, 0), "reduce")
+                if r == 0 and float(t[0]) != W * (W + 1) / 2.0:
+                    raise RuntimeError(f"native reduce returned {float(t[0])}")
+                src = torch.arange(W * 8, dtype=torch.float32, device=dev) + 1000.0 * r
+                piece = torch.empty(8, dtype=torch.float32, device=dev)
+                self._watch(self.native.reduce_scatter(piece, src), "reduce-scatter")
+                want = torch.arange(8, dtype=torch.float32) + 8.0 * r
+                want = want * W + 1000.0 * (W * (W - 1) / 2.0)
+                if not torch.equal(piece.cpu(), want):
+                    raise RuntimeError("native reduce-scatter returned wrong values")
+                full = torch.empty(W * 8, dtype=torch.float32, device=dev)
+                self._watch(self.native.all_gather(full, piece), "all-gather")
+                q = (r + 1) % W                    # the neighbour's piece: (arange(8) + 8 q) * W + 1000 * W (W - 1) / 2
+                if float(full[8 * q]) != 8.0 * q * W + 1000.0 * (W * (W - 1) / 2.0):
+                    raise RuntimeError("native all-gather returned wrong values")
+                # neighbour ring through grouped send/recv: rank r -> r + 1, r - 1 -> r, one group per rank
+                out = torch.full((n,), float(r), dtype=torch.bfloat16, device=dev)
+                inp = torch.full((n,), -1.0, dtype=torch.bfloat16, device=dev)
+                self._watch(self.native.batch_p2p([(True, out, (r + 1) % W), (False, inp, (r - 1) % W)]), "grouped send/recv ring")
+                if float(inp[0]) != float((r - 1) % W) or float(inp[-1]) != float((r - 1) % W):
+                    raise RuntimeError(f"native send/recv ring delivered {float(inp[0])}, expected {float((r - 1) % W)}")
+                # sub-communicators (what build_grid makes for DP x PP): [0, W/2) and [W/2, W) ...
+                half = W // 2
+                lo = r < half
+                sub = self.native.split(0 if lo else 1, r, r if lo else r - half, half if lo else W - half)
+                t = torch.ones(256, dtype=torch.float32, device=dev)
+                sub_w = half if lo else W - half
+                tk = sub.all_reduce(t, 0)
+                import time
+                t0 = time.monotonic()
+                while not sub.query(tk):
+                    if time.monotonic() - t0 > _SELFTEST_TIMEOUT_S:
+                        raise TimeoutError("all-reduce on an ncclCommSplit sub-communicator did not complete")
+                    time.sleep(0.0005)
+                sub.wait(tk)
+                if float(t[0]) != float(sub_w):
+                    raise RuntimeError(f"sub-communicator all-reduce returned {float(t[0])}, expected {sub_w}")
+                sub.synchronize()
+                del sub
+                if W > 2:
+                    # ... and a split that leaves the last rank out (NCCL_SPLIT_NOCOLOR: build_grid's idle ranks)
+                    idle = r == W - 1
+                    sub = self.native.split(-1 if idle else 0, 0 if idle else r, 0 if idle else r, 1 if idle else W - 1)
+                    if idle != (sub is None):
+                        raise RuntimeError("ncclCommSplit with NOCOLOR returned a communicator to the wrong ranks")
+                    if sub is not None:
+                        t = torch.ones(256, dtype=torch.float32, device=dev)
+                        tk = sub.all_reduce(t, 0)
+                        t0 = time.monotonic()
+                        while not sub.query(tk):
+                            if time.monotonic() - t0 > _SELFTEST_TIMEOUT_S:
+                                raise TimeoutError("all-reduce on the NOCOLOR-split sub-communicator did not complete")
+                            time.sleep(0.0005)
+                        sub.wait(tk)
+                        if float(t[0]) != float(W - 1):
+                            raise RuntimeError(f"NOCOLOR-split all-reduce returned {float(t[0])}, expected {W - 1}")
+                        sub.synchronize()
+                        del sub
         except Exception as e:  # noqa: BLE001
             ok, why = False, f"{type(e).__name__}: {e}"
         if strict:
@@ -265,8 +359,10 @@ class Communicator:
                 raise RuntimeError(f"native RCCL communicator failed its self-test: {why}")
             return
         all_ok = ok
-        if self.world_size > 1:
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        if W > 1:
+            # agreement on the control plane: host tensor under gloo, device tensor when c10d itself runs on RCCL
+            on_dev = self._c10d_backend() == "nccl"
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if on_dev else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
             all_ok = bool(int(flag.item()) == 1)
         if not all_ok:
@@ -321,9 +417,26 @@ class Communicator:
 
     @property
     def backend(self) -> str:
-        if self._static is not None:
+        """The transport of DEVICE tensors: "nccl" (= RCCL: the native layer or c10d's ProcessGroupNCCL), "gloo", or
+        "none" without a process group.  (The c10d group under a native communicator is a gloo control plane.)"""
+        if self._static is not None or self.native is not None:
             return "nccl"
-        return dist.get_backend(self.group) if self.initialized else "none"
+        return self._c10d_backend()
+
+    def _c10d_backend(self) -> str:
+        if self._static is not None or not self.initialized:
+            return "none"
+        return dist.get_backend(self.group)
+
+    def _adopt_c10d_nccl(self) -> None:
+        """Fallback of the world communicator when the native layer is unavailable: a c10d RCCL group over the same
+        ranks becomes the carrier of device collectives (collective over the world: every rank calls it)."""
+        try:
+            self.group = dist.new_group(ranks=list(range(dist.get_world_size())), backend="nccl",
+                                        timeout=datetime.timedelta(seconds=self._timeout_s))
+        except TypeError:                      # older signature without timeout
+            self.group = dist.new_group(ranks=list(range(dist.get_world_size())), backend="nccl")
+        self._c10d_sub_backend = "nccl"
 
     def to_global(self, group_rank: int) -> int:
         if self._ranks is None:
@@ -451,10 +564,10 @@ class Communicator:
             self.native.wait(self.native.all_reduce(t, 0))
             torch.cuda.current_stream(self.device).synchronize()
             return
-        if self.backend == "nccl" and self.device is not None:
+        if self._c10d_backend() == "nccl" and self.device is not None:
             dist.barrier(group=self.group, device_ids=[self.device.index])
         else:
-            dist.barrier(group=self.group)
+            dist.barrier(group=self.group)        # host barrier (gloo control plane); callers synchronise their own streams
 
     # ---- point to point (reference: MP.py:140,144,153,167) ----
     def _staged(self, tensor: torch.Tensor) -> bool:
@@ -463,11 +576,40 @@ class Communicator:
         memory only, and its own device-tensor collectives stopped making progress on a 102 MB broadcast on ROCm
         (ResNet-50's flat parameter buffer, two ranks; small tensors worked).  ``DPA_GLOO_DEVICE=native`` hands
         device tensors to gloo's collectives anyway.  Under RCCL nothing ever leaves the device."""
-        return tensor.is_cuda and self.backend != "nccl"
+        return tensor.is_cuda and self._c10d_backend() != "nccl"
+
+    def _native_blocking_p2p(self, ops, what: str) -> None:
+        """One grouped native transfer, waited for on the HOST with a watchdog.  ncclSend / ncclRecv are rendezvous
+        operations on the one communication stream of each rank: a transfer whose peer never posts the matching call -
+        or two ranks that each ``send`` first and ``recv`` second to one another as separate calls - would block that
+        stream forever.  The blocking forms therefore fail loudly after DPA_P2P_TIMEOUT seconds; exchanges in BOTH
+        directions between two ranks belong in ONE group: ``sendrecv`` / ``batch_p2p``."""
+        import time
+        ticket = self.native.batch_p2p(ops)
+        t0 = time.monotonic()
+        while not self.native.query(ticket):
+            if time.monotonic() - t0 > _P2P_TIMEOUT_S:
+                raise TimeoutError(
+                    f"rank {self.global_rank}: {what} did not complete in {_P2P_TIMEOUT_S:.0f} s - unmatched, or both ranks "
+                    f"sent first: pair transfers that cross between two ranks through Communicator.sendrecv / batch_p2p")
+            time.sleep(0.0002)
+        self.native.wait(ticket)
+        if _SYNC_DEBUG:
+            self.native.synchronize()
+
+    def sendrecv(self, send_tensor: torch.Tensor, recv_tensor: torch.Tensor, peer: int, recv_peer: Optional[int] = None):
+        """Send to ``peer`` and receive from ``recv_peer`` (default: the same rank) as ONE grouped call: the
+        deadlock-free form of an exchange, whatever order the other side uses inside its own group."""
+        src = peer if recv_peer is None else recv_peer
+        for w in self.batch_p2p([("send", send_tensor, peer), ("recv", recv_tensor, src)]):
+            w.wait()
 
     def send(self, tensor: torch.Tensor, dst: int):
+        """Blocking send (reference: ``dist.send``, MP.py:140,167).  Between two ranks that exchange in both directions
+        every rank must agree on the order (the reference: rank 0 sends then receives, rank 1 receives then sends);
+        when both would send first, use ``sendrecv``."""
         if self._on_native(tensor):
-            self._native_result(self.native.batch_p2p([(True, tensor, dst)]), False)
+            self._native_blocking_p2p([(True, tensor, dst)], f"send to rank {dst}")
             return
         self._need_c10d("send")
         if self._staged(tensor):
@@ -479,7 +621,7 @@ class Communicator:
 
     def recv(self, tensor: torch.Tensor, src: int):
         if self._on_native(tensor):
-            self._native_result(self.native.batch_p2p([(False, tensor, src)]), False)
+            self._native_blocking_p2p([(False, tensor, src)], f"recv from rank {src}")
             return
         self._need_c10d("recv")
         if self._staged(tensor):
@@ -571,7 +713,7 @@ class Communicator:
             t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
             self.all_reduce(t, op=rop)
             return float(t.item())
-        dev = self.device if (self.device is not None and self.backend == "nccl") else torch.device("cpu")
+        dev = self.device if (self.device is not None and self._c10d_backend() == "nccl") else torch.device("cpu")
         t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=rop, group=self.group)
         return float(t.item())
@@ -589,8 +731,10 @@ class Communicator:
                                static=(ranks.index(self.global_rank) if member else 0, len(ranks)), store=self.store)
             sub.attach_native(parent=self, member=member)
             return sub if member else None
-        group = dist.new_group(ranks=ranks)
+        group = dist.new_group(ranks=ranks, backend=self._c10d_sub_backend)
         sub = Communicator(group=group, device=self.device, ranks=ranks) if member else None
+        if sub is not None:
+            sub._c10d_sub_backend, sub._timeout_s = self._c10d_sub_backend, self._timeout_s
         if self.native is not None:
             if member:
                 sub.attach_native(parent=self, member=True)

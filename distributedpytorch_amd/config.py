@@ -58,6 +58,7 @@ class TrainConfig:
     # ---- model / data ----
     model: str = "mnist_cnn"
     dataset_size: int = 60000
+    data_dir: Optional[str] = None  # MNIST IDX files (train-images-idx3-ubyte ...); absent -> synthetic data of the same shape
     dropout: float = 0.0           # GPT-2: embd / attn / resid dropout probability (the MNIST nets keep the reference's 0.5)
     # ---- engine ----
     bucket_mb: float = 32.0
@@ -65,6 +66,7 @@ class TrainConfig:
     shard_optimizer: bool = False  # ZeRO stage 1 (optim.ShardedSGD)
     graph: bool = True             # DP, small CNN on a GPU: replay forward+backward from a hipGraph
     optimizer: str = "sgd"         # sgd | adamw
+    opt_overlap: str = "auto"      # optimizer per bucket behind its all-reduce during backward: auto (model families where it was measured to pay) | on | off
     accum_steps: int = 1           # micro-steps accumulated locally per optimizer step
     clip_grad_norm: float = 0.0    # global-norm clipping (0 = off)
     warmup_steps: int = 0          # linear LR warm-up; with cosine_steps > 0 (or warm-up alone) a cosine decay follows
@@ -80,6 +82,7 @@ class TrainConfig:
     log_json: Optional[str] = None
     timeout_s: float = 300.0
     sync_debug: bool = False
+    breakdown: bool = False        # per-phase HIP-event timers (forward / backward / exposed comm / optimizer) in the JSONL
     device: str = "auto"           # auto | cuda | cpu
 
     # -------- derived topology (reference: DP.py:170-174) --------
@@ -118,6 +121,12 @@ def _common_flags(p: argparse.ArgumentParser) -> None:
     p.add_argument("--dropout", default=0.0, type=float, help="GPT-2 models: embedding / attention / residual dropout probability")
     p.add_argument("--model", default=None, type=str)
     p.add_argument("--dataset-size", default=60000, type=int)
+    p.add_argument("--data-dir", default=None, type=str,
+                   help="directory holding the MNIST IDX files (the reference's datasets.MNIST('./data'), DP.py:100; "
+                        "never downloaded); without them the MNIST models train on synthetic 1x28x28 data")
+    p.add_argument("--breakdown", action="store_true",
+                   help="time forward / backward / exposed communication / optimizer per step with HIP events and write "
+                        "them to the epoch line and --log-json")
     p.add_argument("--steps-per-epoch", default=None, type=int)
     p.add_argument("--device", default="auto", type=str)
     p.add_argument("--checkpoint", default=None, type=str, help="path to write a state_dict checkpoint")
@@ -127,6 +136,8 @@ def _common_flags(p: argparse.ArgumentParser) -> None:
     p.add_argument("--sync-debug", action="store_true", help="synchronise after every comm op and check grads")
     p.add_argument("--device-data", action="store_true",
                    help="generate the synthetic image batches on the GPU (no host work, no H2D copy)")
+    p.add_argument("--bucket-mb", default=32.0, type=float, help="gradient bucket size of the data-parallel reduction (MiB)")
+    p.add_argument("--first-bucket-mb", default=4.0, type=float, help="size of the first bucket launched during backward (MiB)")
     p.add_argument("--ifname", default=None, type=str,
                    help="network interface for inter-node traffic: exported as NCCL_SOCKET_IFNAME and GLOO_SOCKET_IFNAME "
                         "(the reference's README asks for `export GLOO_SOCKET_IFNAME=eth0` by hand, multinode-MP/README.md:12-14)")
@@ -139,11 +150,12 @@ def dp_parser() -> argparse.ArgumentParser:
     p.add_argument("--dist-url", default="tcp://127.0.0.1:8885", type=str,
                    help="rendezvous url; a bare host:port is accepted")
     p.add_argument("--batch-size", default=128, type=int, help="GLOBAL batch (reference fixes 128, DP.py:109)")
-    p.add_argument("--bucket-mb", default=32.0, type=float)
-    p.add_argument("--first-bucket-mb", default=4.0, type=float)
     p.add_argument("--shard-optimizer", action="store_true", help="optimizer state sharded over the ranks (ZeRO stage 1)")
     p.add_argument("--no-graph", action="store_true", help="small CNN on a GPU: do not replay the step from a hipGraph")
     p.add_argument("--optimizer", default="sgd", choices=["sgd", "adamw"])
+    p.add_argument("--opt-overlap", default="auto", choices=["auto", "on", "off"],
+                   help="update each gradient bucket behind its all-reduce while backward is still running "
+                        "(constant-lr SGD without clipping only); auto = the model families where it was measured to pay")
     p.add_argument("--accum-steps", default=1, type=int, help="gradient accumulation: micro-steps per optimizer step")
     p.add_argument("--clip-grad-norm", default=0.0, type=float, help="global gradient-norm clipping (0 = off)")
     p.add_argument("--warmup-steps", default=0, type=int, help="linear LR warm-up steps (then cosine decay)")
@@ -187,13 +199,15 @@ def config_from_args(args: argparse.Namespace, mode: str) -> TrainConfig:
         steps_per_epoch=args.steps_per_epoch, device=args.device,
         checkpoint=args.checkpoint, resume=args.resume, log_json=args.log_json,
         timeout_s=args.timeout, sync_debug=args.sync_debug, device_data=args.device_data,
+        data_dir=args.data_dir, breakdown=args.breakdown,
     )
+    cfg.bucket_mb = args.bucket_mb
+    cfg.first_bucket_mb = args.first_bucket_mb
     if mode == "dp":
-        cfg.bucket_mb = args.bucket_mb
-        cfg.first_bucket_mb = args.first_bucket_mb
         cfg.shard_optimizer = args.shard_optimizer
         cfg.graph = not args.no_graph
         cfg.optimizer, cfg.accum_steps, cfg.clip_grad_norm = args.optimizer, args.accum_steps, args.clip_grad_norm
+        cfg.opt_overlap = args.opt_overlap
         cfg.warmup_steps, cfg.cosine_steps, cfg.min_lr = args.warmup_steps, args.cosine_steps, args.min_lr
     else:
         cfg.micro_batches = args.micro_batches

@@ -485,8 +485,11 @@ __global__ __launch_bounds__(256) void reduce_shards_bf16_kernel(float* __restri
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float a = dst[i];
         for (int k = 0; k < nsrc; ++k) a += bf16_to_float(src[(long)k * stride + i]);
-        dst[i] = a;
-        out[i] = float_to_bf16(a);
+        // the owner keeps the ROUNDED sum too: every peer receives bf16(a) and widens it, and data-parallel replicas
+        // must hold bit-identical gradients (else their fp32 masters drift apart step by step)
+        const unsigned short r = float_to_bf16(a);
+        dst[i] = bf16_to_float(r);
+        out[i] = r;
     }
 }
 

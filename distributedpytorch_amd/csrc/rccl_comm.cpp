@@ -127,6 +127,8 @@ class RcclComm {
     // ordered by `key`.  Collective over THIS communicator.
     std::unique_ptr<RcclComm> split(int color, int key, int new_rank, int new_world) {
         c10::hip::HIPGuardMasqueradingAsCUDA guard(dev());
+        // ncclCommSplit exists since NCCL 2.18; its prototype is declared by hand above, so ask the library itself
+        TORCH_CHECK(version() >= 21800, "ncclCommSplit needs RCCL >= 2.18 (library reports ", version(), ")");
         ncclComm_t sub = nullptr;
         RCCL_CHECK(ncclCommSplit(comm_, color < 0 ? -1 : color, key, &sub, nullptr));   // -1 = NCCL_SPLIT_NOCOLOR
         if (color < 0 || sub == nullptr) return nullptr;
@@ -176,12 +178,17 @@ class RcclComm {
     // receive between neighbours cannot deadlock
     int64_t batch_p2p(const std::vector<std::tuple<bool, Tensor, int>>& ops) {
         std::vector<Tensor> keep;
+        int64_t self_send = 0, self_recv = 0;     // elements sent to / received from this rank itself inside the group
         for (auto& o : ops) {
             check(std::get<1>(o));
             const int peer = std::get<2>(o);
-            TORCH_CHECK(peer >= 0 && peer < world_ && peer != rank_, "batch_p2p: bad peer ", peer);
+            TORCH_CHECK(peer >= 0 && peer < world_, "batch_p2p: bad peer ", peer);
+            if (peer == rank_) (std::get<0>(o) ? self_send : self_recv) += std::get<1>(o).numel();
             keep.push_back(std::get<1>(o));
         }
+        // a transfer to oneself is legal only as a matched send + receive inside ONE group (RCCL then copies locally);
+        // a lone one would wait for a peer that cannot arrive
+        TORCH_CHECK(self_send == self_recv, "batch_p2p: a send to this rank itself needs the matching receive in the same group");
         begin();
         RCCL_CHECK(ncclGroupStart());
         for (auto& o : ops) {

@@ -101,6 +101,107 @@ class SyntheticImageDataset:
         return x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
 
 
+MNIST_MEAN, MNIST_STD = 0.1307, 0.3081      # transforms.Normalize((0.1307,), (0.3081,)), DP.py:105 / MP.py:107
+
+
+def _read_idx(path: str) -> torch.Tensor:
+    """One IDX file (the MNIST distribution format; ``.gz`` accepted): magic = 0, 0, type code, rank; big-endian
+    uint32 dims; row-major payload.  Only the unsigned-byte type (0x08) MNIST uses is read."""
+    import gzip
+    import struct
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rb") as f:
+        head = f.read(4)
+        if len(head) != 4 or head[0] != 0 or head[1] != 0:
+            raise ValueError(f"{path}: not an IDX file (magic {head!r})")
+        if head[2] != 0x08:
+            raise ValueError(f"{path}: IDX element type 0x{head[2]:02x} is not unsigned byte")
+        rank = head[3]
+        dims = struct.unpack(">" + "I" * rank, f.read(4 * rank))
+        count = 1
+        for d in dims:
+            count *= d
+        payload = f.read(count)
+        if len(payload) != count:
+            raise ValueError(f"{path}: truncated IDX payload ({len(payload)} of {count} bytes)")
+    return torch.frombuffer(bytearray(payload), dtype=torch.uint8).reshape(dims)
+
+
+def find_mnist(root: Optional[str], train: bool = True) -> Optional[Tuple[str, str]]:
+    """(images, labels) IDX paths of the MNIST split under ``root`` - in ``root`` itself, ``root/MNIST/raw``
+    (torchvision's layout: ``datasets.MNIST('./data', download=True)``, DP.py:100) or ``root/raw`` - or None.
+    Never downloads."""
+    import os
+    if not root:
+        return None
+    stem = "train" if train else "t10k"
+    for sub in ("", os.path.join("MNIST", "raw"), "raw"):
+        for sep in ("-", "."):
+            for ext in ("", ".gz"):
+                img = os.path.join(root, sub, f"{stem}-images{sep}idx3-ubyte{ext}")
+                lab = os.path.join(root, sub, f"{stem}-labels{sep}idx1-ubyte{ext}")
+                if os.path.isfile(img) and os.path.isfile(lab):
+                    return img, lab
+    return None
+
+
+class MNISTIdx:
+    """The reference's dataset (multinode-DP/multinodeDP.py:100-107, multinode-MP/multinodeMP.py:104-110): MNIST from
+    its IDX files with ``ToTensor()`` + ``Normalize((0.1307,), (0.3081,))``.  There is no torchvision and no network
+    here, so the files are the user's (``--data-dir``); nothing is ever downloaded.  The whole split (47 MB of bytes)
+    is held as one uint8 tensor and normalised per batch - on the GPU when ``device`` is one, so the host only
+    gathers bytes."""
+
+    shape, classes = (1, 28, 28), 10
+
+    def __init__(self, root: str, train: bool = True, device: Optional[torch.device] = None):
+        paths = find_mnist(root, train)
+        if paths is None:
+            raise FileNotFoundError(f"no MNIST IDX files ({'train' if train else 't10k'}-images-idx3-ubyte[.gz] + "
+                                    f"labels) under {root!r}")
+        self.images = _read_idx(paths[0])                   # [n, 28, 28] uint8
+        self.labels = _read_idx(paths[1]).to(torch.long)    # [n]
+        if self.images.dim() != 3 or self.images.shape[0] != self.labels.shape[0]:
+            raise ValueError(f"{paths[0]}: {tuple(self.images.shape)} images vs {tuple(self.labels.shape)} labels")
+        self.shape = (1,) + tuple(self.images.shape[1:])
+        self.n = int(self.images.shape[0])
+        self.device = device or torch.device("cpu")
+        self.paths = paths
+
+    def __len__(self) -> int:
+        return self.n
+
+    @staticmethod
+    def _normalise(raw: torch.Tensor) -> torch.Tensor:
+        # ToTensor: uint8 -> [0, 1] float, channel axis first; Normalize: (x - mean) / std
+        return raw.to(torch.float32).div_(255.0).sub_(MNIST_MEAN).div_(MNIST_STD).unsqueeze(-3)
+
+    def __getitem__(self, i: int):
+        return self._normalise(self.images[i]), int(self.labels[i])
+
+    def batch(self, indices: Sequence[int]):
+        idx = torch.as_tensor(list(indices), dtype=torch.long)
+        raw, y = self.images[idx], self.labels[idx]
+        if self.device.type == "cuda":
+            raw, y = raw.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True)
+        return self._normalise(raw), y
+
+
+def mnist_or_synthetic(data_dir: Optional[str], n: int = 60000, seed: int = 1234, device: Optional[torch.device] = None,
+                       on_device: bool = False, log=None):
+    """The training set of the two reference scripts: real MNIST when ``data_dir`` holds the IDX files, else the
+    synthetic MNIST-shaped set (and say which)."""
+    if data_dir:
+        if find_mnist(data_dir, True) is not None:
+            ds = MNISTIdx(data_dir, True, device=device if on_device else None)
+            if log is not None:
+                log(f"MNIST: {len(ds)} images from {ds.paths[0]}")
+            return ds
+        if log is not None:
+            log(f"no MNIST IDX files under {data_dir!r}: synthetic 1x28x28 data instead")
+    return SyntheticImageDataset(n=n, shape=(1, 28, 28), classes=10, seed=seed, device=device, on_device=on_device)
+
+
 class SyntheticTokenDataset:
     """Token sequences for GPT-2 shaped workloads: ``(tokens[S], targets[S])``."""
 

@@ -100,6 +100,11 @@ class PhaseTimer:
                 self._pairs.setdefault(name, []).append(time.perf_counter() - t0)
                 _roctx_pop(rng)
 
+    def summary_with_counts(self, reset: bool = True):
+        """(mean milliseconds per occurrence, number of occurrences) of each phase."""
+        counts = {name: len(vals) for name, vals in self._pairs.items() if vals}
+        return self.summary(reset), counts
+
     def summary(self, reset: bool = True) -> Dict[str, float]:
         """Mean milliseconds per occurrence of each phase."""
         out = {}

@@ -142,6 +142,10 @@ class Embedding(nn.Module):
 
 
 class GPT2(nn.Module):
+    # FusedSGD.overlap_with_backward was measured to pay on this family (+0.9 % on one GPU; the ResNets lose 0.3 %:
+    # their step is HBM-bound throughout) - what train.run_dp's --opt-overlap auto and bench.py consult
+    optimizer_overlap_pays = True
+
     def __init__(self, cfg: GPT2Config = GPT2Config()):
         super().__init__()
         self.cfg = cfg

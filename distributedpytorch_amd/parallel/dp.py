@@ -80,7 +80,7 @@ class DataParallel:
         self._armed = False
         self._launched: List[Bucket] = []
         self._next_bucket = 0
-        self.stats = {"allreduce_calls": 0, "allreduce_bytes": 0}
+        self.stats = {"allreduce_calls": 0, "allreduce_bytes": 0, "bucket_launches": 0}
         # called with a bucket right after its reduction has been ISSUED (b.work is the handle): optim.FusedSGD's
         # overlapped mode updates the bucket's parameters behind it, while backward is still running
         self.bucket_hook = None
@@ -182,8 +182,13 @@ class DataParallel:
         else:
             b.work = self.comm.all_reduce(view, async_op=True)
         self._launched.append(b)
-        self.stats["allreduce_calls"] += 1
-        self.stats["allreduce_bytes"] += view.numel() * 4
+        self.stats["bucket_launches"] += 1
+        # only collectives that were really issued count: a single process without a process group (bench.py at N = 1)
+        # gets stand-in handles from Communicator.all_reduce and moves no bytes
+        done = b.work.works if isinstance(b.work, _Works) else [b.work]
+        if any(not isinstance(w, _comm._DoneWork) for w in done):
+            self.stats["allreduce_calls"] += 1
+            self.stats["allreduce_bytes"] += view.numel() * 4
         if self.bucket_hook is not None:
             self.bucket_hook(b)
 

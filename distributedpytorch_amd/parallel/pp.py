@@ -18,6 +18,7 @@ gradients inside its replica group.
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -63,9 +64,39 @@ def param_costs(layers: Sequence[nn.Module]) -> List[float]:
     return [1.0 + sum(p.numel() for p in l.parameters()) for l in layers]
 
 
-def measure_costs(layers: Sequence[nn.Module], sample: torch.Tensor, iters: int = 3) -> List[float]:
+class _PreserveState:
+    """Train-mode passes over the REAL layers (timing, shape tracing) put back what they touch besides gradients:
+    BatchNorm running statistics / batch counters and the positions of the counter-based dropout streams - measuring
+    must not change the run that follows."""
+
+    def __init__(self, layers: Sequence[nn.Module]):
+        self.layers = layers
+
+    def __enter__(self):
+        self.bufs = [(b, b.detach().clone()) for layer in self.layers for b in layer.buffers()]
+        self.drop = [(m._drop, {k: getattr(m._drop, k) for k in ("calls", "step") if hasattr(m._drop, k)})
+                     for layer in self.layers for m in layer.modules() if getattr(m, "_drop", None) is not None]
+        return self
+
+    def __exit__(self, *exc):
+        with torch.no_grad():
+            for b, keep in self.bufs:
+                b.copy_(keep)
+        for drop, fields in self.drop:
+            for k, v in fields.items():
+                setattr(drop, k, v)
+        return False
+
+
+Meta = Tuple[Tuple[int, ...], torch.dtype]      # trailing shape (without the batch axis) and dtype of a stage boundary
+
+
+def measure_costs(layers: Sequence[nn.Module], sample: torch.Tensor, iters: int = 3,
+                  metas: Optional[List[Meta]] = None) -> List[float]:
     """Forward+backward time of every layer on this device (stages must be balanced by
-    TIME, not by layer count: early ResNet stages move far more activation bytes)."""
+    TIME, not by layer count: early ResNet stages move far more activation bytes).  ``metas`` (a list) receives the
+    trailing shape and dtype of every layer's OUTPUT: what a stage needs to post its receives without any wire
+    negotiation (``PipelineStage(in_meta=...)``)."""
     costs = []
     x = sample
     use_cuda = sample.is_cuda
@@ -76,26 +107,46 @@ def measure_costs(layers: Sequence[nn.Module], sample: torch.Tensor, iters: int 
         y.backward(torch.ones_like(y) if g is None else g)
         return y
 
-    for layer in layers:
-        # one untimed forward AND backward first: the first launch of a kernel loads its code object (milliseconds),
-        # and whichever layer meets a kernel first would be charged for it - a split measured that way put 49 of
-        # ResNet-152's 52 layers on the last of 4 stages
-        y = once(layer, x, None)
-        g = torch.ones_like(y)
-        best = float("inf")
-        for _ in range(max(1, iters)):
-            if use_cuda:
-                torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            once(layer, x, g)
-            if use_cuda:
-                torch.cuda.synchronize()
-            best = min(best, time.perf_counter() - t0)      # min, not mean: a neighbour's burst or a host hiccup only adds
-        costs.append(best)
-        x = y.detach()
-        for p in layer.parameters():
-            p.grad = None
+    with _PreserveState(layers):
+        for layer in layers:
+            # one untimed forward AND backward first: the first launch of a kernel loads its code object (milliseconds),
+            # and whichever layer meets a kernel first would be charged for it - a split measured that way put 49 of
+            # ResNet-152's 52 layers on the last of 4 stages
+            y = once(layer, x, None)
+            g = torch.ones_like(y)
+            best = float("inf")
+            for _ in range(max(1, iters)):
+                if use_cuda:
+                    torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                once(layer, x, g)
+                if use_cuda:
+                    torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t0)      # min, not mean: a neighbour's burst or a host hiccup only adds
+            costs.append(best)
+            if metas is not None:
+                metas.append((tuple(int(d) for d in y.shape[1:]), y.dtype))
+            x = y.detach()
+            for p in layer.parameters():
+                p.grad = None
     return costs
+
+
+def trace_shapes(layers: Sequence[nn.Module], sample: torch.Tensor) -> List[Meta]:
+    """Trailing shape + dtype of every layer's output, from one no-grad pass of a small sample (where nothing is
+    timed: the CPU path, whose stages are cut by parameter count)."""
+    metas: List[Meta] = []
+    x = sample
+    with _PreserveState(layers), torch.no_grad():
+        for layer in layers:
+            x = layer(x)
+            metas.append((tuple(int(d) for d in x.shape[1:]), x.dtype))
+    return metas
+
+
+def stage_in_metas(metas: Sequence[Meta], bounds: Sequence[Tuple[int, int]]) -> List[Optional[Meta]]:
+    """Per stage: the meta of what it receives (None for stage 0) = the output of the layer before its first one."""
+    return [None if a == 0 else (tuple(metas[a - 1][0]), metas[a - 1][1]) for a, _ in bounds]
 
 
 def split_microbatches(n: int, n_micro: int) -> List[int]:
@@ -149,18 +200,30 @@ class PipelineStage:
     """
 
     def __init__(self, module: nn.Module, comm: _comm.Communicator, loss_fn: Optional[Callable] = None,
-                 n_micro: int = 1, schedule: str = "1f1b", dp=None, send_dtype: Optional[torch.dtype] = None):
+                 n_micro: int = 1, schedule: str = "1f1b", dp=None, send_dtype: Optional[torch.dtype] = None,
+                 in_meta: Optional[Meta] = None, negotiate: bool = True, tied_wire: Optional[str] = None):
+        """``negotiate`` (the same on EVERY stage of a pipeline): True = each stage learns the trailing shape and dtype
+        of its input from one small transfer in front of the first activation; False = nothing is negotiated on the
+        wire, as in the reference (both of its ranks know ``[B, 320]`` fp32, MP.py:143,152): every receiving stage is
+        given ``in_meta`` by the caller (``measure_costs`` / ``trace_shapes`` + ``stage_in_metas``)."""
         self.module, self.comm, self.loss_fn, self.dp = module, comm, loss_fn, dp
         self.stage, self.n_stages = comm.rank, comm.world_size
         self.n_micro, self.schedule = n_micro, schedule
         self.first, self.last = self.stage == 0, self.stage == self.n_stages - 1
         self.send_dtype = send_dtype
         self.device = next(module.parameters()).device
-        self._in_meta: Optional[Tuple[Tuple[int, ...], torch.dtype]] = None   # trailing shape + dtype of inputs
+        self._negotiate = bool(negotiate)
+        if not self._negotiate and not self.first and in_meta is None:
+            raise ValueError("PipelineStage(negotiate=False): a receiving stage needs in_meta")
+        self._in_meta: Optional[Meta] = (tuple(in_meta[0]), in_meta[1]) if (in_meta is not None and not self._negotiate) else None
         self._out_meta_sent = False
         self._pending_sends: List = []
         self._slots = _SlotPool()
         self.last_loss: Optional[torch.Tensor] = None
+        self.timer = None                      # metrics.PhaseTimer: forward / backward / p2p phases per micro-batch
+        self._tied_wire = (tied_wire or os.environ.get("DPA_TIED_WIRE", "auto")).lower()
+        self._tied_buf: Dict[str, torch.Tensor] = {}
+        self.peak_live = _sched.peak_live_microbatches(schedule, self.n_stages, self.stage, max(1, n_micro))
         # parameters tied across the first and the last stage (GPT-2's wte: embedding + LM head).  A stage holding only
         # one end exchanges that parameter's gradient with the other end after backward (see _sync_tied)
         ends: Dict[str, Dict[str, nn.Parameter]] = {}
@@ -171,23 +234,29 @@ class PipelineStage:
         self._tied = [(name, roles["first" if "first" in roles else "last"], "first" if "first" in roles else "last")
                       for name, roles in sorted(ends.items()) if len(roles) == 1 and self.n_stages > 1]
 
-    # ---- shape negotiation: once, trailing dims only (the batch dim comes from the data) ----
+    # ---- shape negotiation (only when the caller gave no ``in_meta``): once, trailing dims only ----
     def _send_meta(self, y: torch.Tensor) -> None:
         meta = torch.zeros(8, dtype=torch.int64)
         trailing = list(y.shape[1:])
         meta[0] = len(trailing)
         for i, d in enumerate(trailing):
             meta[1 + i] = d
-        meta[7] = _DTYPES.index(y.dtype)
-        self.comm.send(meta.to(self.device), self.stage + 1)
+        meta[7] = _DTYPES.index(y.dtype if self.send_dtype is None else self.send_dtype)
+        buf = meta.to(self.device)
+        for w in self.comm.batch_p2p([("send", buf, self.stage + 1)]):
+            w.wait()
         self._out_meta_sent = True
 
     def _recv_meta(self) -> None:
         meta = torch.zeros(8, dtype=torch.int64, device=self.device)
-        self.comm.recv(meta, self.stage - 1)
-        meta = meta.cpu()
+        for w in self.comm.batch_p2p([("recv", meta, self.stage - 1)]):
+            w.wait()
+        meta = meta.cpu()                      # one host read, once per run
         nd = int(meta[0])
         self._in_meta = (tuple(int(v) for v in meta[1:1 + nd]), _DTYPES[int(meta[7])])
+
+    def _phase(self, name: str):
+        return self.timer.phase(name) if self.timer is not None else _NullCtx()
 
     # ---- one training step over a (possibly ragged) batch ----
     def train_step(self, batch_size: int, x: Optional[torch.Tensor] = None, target: Optional[torch.Tensor] = None):
@@ -200,45 +269,50 @@ class PipelineStage:
         offs = [0]
         for s in sizes:
             offs.append(offs[-1] + s)
-        ops = _sched.build_schedule(self.schedule, self.n_stages, self.stage, n_micro)
-        steps = _sched.group_comm(ops)
+        # compute operations alone, communication in groups that are deadlock-free under rendezvous semantics on one
+        # in-order stream per rank, even if whole groups had to pair up (schedule.validate_rendezvous, strict)
+        steps = _sched.build_steps(self.schedule, self.n_stages, self.stage, n_micro)
         inputs: Dict[int, torch.Tensor] = {}
         outputs: Dict[int, torch.Tensor] = {}
         grads_in: Dict[int, torch.Tensor] = {}
         loss_sum = None
         n_b_done = 0
-        if not self.first and self._in_meta is None:
+        if self._negotiate and not self.first and self._in_meta is None:
             self._recv_meta()
+        send_meta = (not self.last) and (not self._out_meta_sent) and self._sends_meta()
 
         for step in steps:
             kind = step[0][0]
             if kind in _sched.COMM_OPS:
-                self._run_comm(step, sizes, inputs, outputs, grads_in)
+                with self._phase("p2p"):
+                    self._run_comm(step, sizes, inputs, outputs, grads_in)
                 continue
             op, mb = step[0]
             if op == "F":
-                if self.first:
-                    xin = x[offs[mb]:offs[mb + 1]]
-                else:
-                    xin = inputs[mb]
-                    if xin.is_floating_point():
-                        xin.requires_grad_(True)
-                    inputs[mb] = xin
-                y = self.module(xin)
-                if self.last:
-                    t = target[offs[mb]:offs[mb + 1]]
-                    loss = self.loss_fn(y, t) * (sizes[mb] / float(batch_size))
-                    outputs[mb] = loss
-                    loss_sum = loss.detach() if loss_sum is None else loss_sum + loss.detach()
-                else:
-                    outputs[mb] = y
-                    if not self._out_meta_sent:
-                        self._send_meta(y)
+                with self._phase("forward"):
+                    if self.first:
+                        xin = x[offs[mb]:offs[mb + 1]]
+                    else:
+                        xin = inputs[mb]
+                        if xin.is_floating_point():
+                            xin.requires_grad_(True)
+                        inputs[mb] = xin
+                    y = self.module(xin)
+                    if self.last:
+                        t = target[offs[mb]:offs[mb + 1]]
+                        loss = self.loss_fn(y, t) * (sizes[mb] / float(batch_size))
+                        outputs[mb] = loss
+                        loss_sum = loss.detach() if loss_sum is None else loss_sum + loss.detach()
+                    else:
+                        outputs[mb] = y
+                if send_meta:
+                    self._send_meta(y)
+                    send_meta = False
             else:  # "B"
                 n_b_done += 1
                 sync_now = n_b_done == n_micro
                 ctx = self.dp.no_sync() if (self.dp is not None and not sync_now) else _NullCtx()
-                with ctx:
+                with self._phase("backward"), ctx:
                     if self.last:
                         outputs.pop(mb).backward()
                     else:
@@ -247,32 +321,80 @@ class PipelineStage:
                         self._slots.give(g_in)
                 if self.first:
                     inputs.pop(mb, None)
-        for w in self._pending_sends:
-            w[0].wait()
-        self._pending_sends.clear()
+        with self._phase("p2p"):
+            for w in self._pending_sends:
+                w[0].wait()
+            self._pending_sends.clear()
         if self.dp is not None:
-            self.dp.finish()
-        self._sync_tied()
+            with self._phase("dp_exposed"):
+                self.dp.finish()
+        with self._phase("tied_sync"):
+            self._sync_tied()
         self.last_loss = loss_sum
         return loss_sum
+
+    def _sends_meta(self) -> bool:
+        return self._negotiate
+
+    def _tied_wire_dtype(self, g: torch.Tensor) -> torch.dtype:
+        if self._tied_wire in ("bf16", "bfloat16"):
+            return torch.bfloat16
+        if self._tied_wire in ("fp32", "float32"):
+            return torch.float32
+        # auto: bf16 on the links when the model computes in bf16 on a GPU (the gradient of a bf16 GEMM carries no more
+        # than that), the parameter's own dtype elsewhere (CPU oracles compare to fp32 rounding)
+        return torch.bfloat16 if (g.is_cuda and g.dtype == torch.float32) else g.dtype
 
     def _sync_tied(self) -> None:
         """Sum the gradients of a parameter whose two uses sit on the first and the last stage (Megatron's embedding
         all-reduce, as two transfers over the pipeline group: last -> first, sum, first -> last).  After the replica
         all-reduce (both are sums, the order is free), before the optimizers - which then apply the same update to both
-        copies."""
-        for _name, p, role in self._tied:
+        copies.  The wire buffer is persistent (GPT-2's wte: 154 MB in fp32 - not allocated per step) and carries bf16
+        with fp32 accumulation on the GPU; BOTH ends keep the value that travelled back (the rounded sum), so the two
+        copies of the parameter stay bit-identical."""
+        for name, p, role in self._tied:
             g = p.grad
             if g is None:
                 g = p.grad = torch.zeros_like(p)
+            wdt = self._tied_wire_dtype(g)
+            wire = self._tied_buf.get(name)
+            if wire is None or wire.shape != g.shape or wire.dtype != wdt:
+                wire = self._tied_buf[name] = torch.empty(g.shape, dtype=wdt, device=g.device)
+            other = self.n_stages - 1 if role == "first" else 0
             if role == "last":
-                self.comm.send(g, 0)
-                self.comm.recv(g, 0)
+                wire.copy_(g)
+                for w in self.comm.batch_p2p([("send", wire, other)]):
+                    w.wait()
+                for w in self.comm.batch_p2p([("recv", wire, other)]):
+                    w.wait()
+                g.copy_(wire)
             else:
-                other = torch.empty_like(g)
-                self.comm.recv(other, self.n_stages - 1)
-                g.add_(other)
-                self.comm.send(g, self.n_stages - 1)
+                for w in self.comm.batch_p2p([("recv", wire, other)]):
+                    w.wait()
+                g.add_(wire)                   # fp32 accumulate of the widened wire values
+                wire.copy_(g)
+                if wdt != g.dtype:
+                    g.copy_(wire)              # keep exactly what the other end will hold
+                for w in self.comm.batch_p2p([("send", wire, other)]):
+                    w.wait()
+
+    def stats(self) -> Dict[str, float]:
+        """What the last steps looked like from this stage (``timer`` set): mean busy milliseconds per step (forward +
+        backward kernels of all micro-batches), time in point-to-point waits, the schedule's theoretical bubble and
+        its peak number of live micro-batches."""
+        out: Dict[str, float] = {"stage": self.stage, "peak_live_microbatches": self.peak_live,
+                                 "bubble_fraction_theory": _sched.bubble_fraction(self.n_stages, max(1, self.n_micro)),
+                                 "slots_allocated": self._slots.allocated}
+        if self.timer is not None:
+            per_occ, counts = self.timer.summary_with_counts()
+            steps = max(1, counts.get("tied_sync", 1))
+            for k in ("forward", "backward", "p2p", "dp_exposed", "tied_sync"):
+                if k in per_occ:
+                    out[k + "_ms_per_step"] = round(per_occ[k] * counts[k] / steps, 4)
+            out["busy_ms_per_step"] = round(out.get("forward_ms_per_step", 0.0) + out.get("backward_ms_per_step", 0.0), 4)
+        if self.device.type == "cuda":
+            out["max_memory_allocated_gb"] = round(torch.cuda.max_memory_allocated(self.device) / 2 ** 30, 3)
+        return out
 
     def _run_comm(self, step, sizes, inputs, outputs, grads_in) -> None:
         batch_ops = []
@@ -379,30 +501,45 @@ def run_pipeline_bench(args, world: _comm.Communicator, device: torch.device) ->
         layers = mnist.mnist_stages()
         stage_mod = layers[stage].to(device).train()
         bounds = [(0, 1), (1, 2)]
+        in_metas = [None, ((320,), torch.float32)]             # [B, 320] fp32: both ranks of the reference know it (MP.py:143,152)
         model = None
     elif tokens:
         from ..models import gpt2
         model = gpt2.gpt2_small()
         classes, seq = model.cfg.vocab_size, args.seq_len
-        batch = args.batch or 8
+        batch = args.batch or 8 * args.micro_batches      # >= 8 sequences of 1024 tokens per micro-batch
         t = torch.randint(0, classes, (batch, seq + 1), generator=g, device=device)
         x, y = t[:, :-1].contiguous(), t[:, 1:].contiguous()
     else:
         model = resnet.tiny_resnet() if name == "tiny_resnet" else getattr(resnet, name)()
         hw, classes = (64, 16) if name == "tiny_resnet" else (224, 1000)
-        batch = args.batch or 256
+        # per-replica batch sized so that a MICRO-batch is >= 128 images: below that the conv kernels run under-filled
+        # grids and pay their fixed costs per launch (docs/DESIGN.md section 10); 288 GB of HBM per stage allow it
+        batch = args.batch or 128 * args.micro_batches
         x = torch.randn(batch, 3, hw, hw, generator=g, device=device)
         y = torch.randint(0, classes, (batch,), generator=g, device=device)
     if not small:
         model = model.to(device).train()
         layers = model.pipeline_layers()
         mb = max(1, batch // args.micro_batches)
-        costs = measure_costs(layers, x[:mb]) if device.type == "cuda" else param_costs(layers)
-        # every rank must agree on the split: use stage 0 / replica 0's measurement
-        costs = world.broadcast_object(costs, src=0)
+        metas: List[Meta] = []
+        if device.type == "cuda":
+            costs = measure_costs(layers, x[:mb], metas=metas)
+        else:
+            costs, metas = param_costs(layers), trace_shapes(layers, x[:2])
+        # every rank must agree on the split: use stage 0 / replica 0's measurement (and its boundary shapes)
+        costs, metas = world.broadcast_object((costs, [(list(sh), _DTYPES.index(dt)) for sh, dt in metas]), src=0)
+        metas = [(tuple(sh), _DTYPES[di]) for sh, di in metas]
         bounds = partition_balanced(costs, S)
+        in_metas = stage_in_metas(metas, bounds)
         stage_mod = build_stage_module(layers, bounds, stage, model)
-        del model
+        if device.type == "cuda":        # the other stages' layers leave this GPU
+            keep = {id(p) for p in stage_mod.parameters()} | {id(b) for b in stage_mod.buffers()}
+            for t_ in list(model.parameters()) + list(model.buffers()):
+                if id(t_) not in keep:
+                    t_.data = torch.empty(0, dtype=t_.dtype)
+            torch.cuda.empty_cache()
+        del model, layers
     dp = DataParallel(stage_mod, dp_comm, bucket_mb=args.bucket_mb, first_bucket_mb=args.first_bucket_mb,
                       use_sink=not args.no_sink, use_lp=not small)
     if small:
@@ -413,7 +550,10 @@ def run_pipeline_bench(args, world: _comm.Communicator, device: torch.device) ->
         opt = FusedSGD(dp.flat, lr=0.1, momentum=0.9, weight_decay=1e-4)
         loss_fn = (lambda out, t: ops.softmax_cross_entropy(out.reshape(-1, out.shape[-1]), t.reshape(-1), classes))
     opt.grad_scale = dp.grad_scale
-    eng = PipelineStage(stage_mod, pp_comm, loss_fn, n_micro=args.micro_batches, schedule=args.schedule, dp=dp)
+    eng = PipelineStage(stage_mod, pp_comm, loss_fn, n_micro=args.micro_batches, schedule=args.schedule, dp=dp,
+                        in_meta=in_metas[stage], negotiate=False)
+    from ..metrics import PhaseTimer
+    eng.timer = PhaseTimer(device)       # a few dozen HIP events per step: forward / backward / p2p per micro-batch
 
     def step():
         loss = eng.train_step(batch, x if eng.first else None, y if eng.last else None)
@@ -422,6 +562,9 @@ def run_pipeline_bench(args, world: _comm.Communicator, device: torch.device) ->
 
     for _ in range(args.warmup):
         step()
+    eng.timer.summary()                  # drop the warm-up's samples
+    if device.type == "cuda":
+        torch.cuda.reset_peak_memory_stats(device)
     world.barrier()
     if device.type == "cuda":
         torch.cuda.synchronize()
@@ -437,6 +580,22 @@ def run_pipeline_bench(args, world: _comm.Communicator, device: torch.device) ->
     # the loss lives on the last stage; make rank 0 report it
     lossv = world.all_reduce_scalar(lossv if eng.last and replica == 0 else 0.0, "sum")
     shape = {"seq_len": seq} if tokens else {"image": f"{1 if small else 3}x{hw}x{hw}"}
+    # one line per stage of replica 0 explains the run: busy time (forward + backward kernels of all micro-batches),
+    # point-to-point waits, peak live micro-batches, peak memory - and the measured bubble beside the schedule's
+    st = eng.stats()
+    st["replica"] = replica
+    all_stats = world.gather_object(st, dst=0)
+    ms_step = 1000.0 * elapsed / max(1, args.steps)
+    if all_stats is not None:
+        per_stage = sorted((d for d in all_stats if d.get("replica") == 0), key=lambda d: d["stage"])
+        busiest = max((d.get("busy_ms_per_step", 0.0) for d in per_stage), default=0.0)
+        pipeline_stats = {"stages": per_stage, "bubble_fraction_theory": _sched.bubble_fraction(S, max(1, args.micro_batches)),
+                          "bubble_fraction_measured": (round(1.0 - busiest / ms_step, 4) if busiest > 0 and ms_step > 0 else None),
+                          "peak_live_microbatches": [d["peak_live_microbatches"] for d in per_stage],
+                          "micro_batch_size": max(1, batch // args.micro_batches)}
+    else:
+        pipeline_stats = None
+    shape["pipeline"] = pipeline_stats
     return {"elapsed": elapsed, "items_per_rank_step": batch * (seq if tokens else 1), "dp_world": replicas, "loss": lossv,
             "config": dict({"model": "gpt2-small-124M" if tokens else ("mnist_cnn (Net1 | Net2)" if small else name),
                             "global_batch": batch * replicas, "slots_allocated": eng._slots.allocated,

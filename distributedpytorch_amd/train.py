@@ -55,6 +55,11 @@ def build_model(name: str, dropout: float = 0.0):
     raise ValueError(f"unknown model {name!r}")
 
 
+def _rank0_print(msg: str) -> None:
+    if int(os.environ.get("RANK", "0")) == 0 and os.environ.get("DPA_QUIET", "0") != "1":
+        print(f"[data] {msg}", flush=True)
+
+
 def build_dataset(kind: str, cfg: TrainConfig, classes: int, model=None, device=None):
     # the dataset lives on the GPU only with --device-data; otherwise it stays on the host and data.PrefetchLoader
     # pins each batch and copies it on its own stream (a device handed to a host dataset made every batch a pageable
@@ -62,7 +67,8 @@ def build_dataset(kind: str, cfg: TrainConfig, classes: int, model=None, device=
     on_device = device is not None and device.type == "cuda" and cfg.device_data
     gen = dict(device=device if on_device else None, on_device=on_device)
     if kind == "mnist":
-        return ddata.SyntheticImageDataset(cfg.dataset_size, (1, 28, 28), 10, cfg.seed, **gen)
+        # the reference's dataset (DP.py:100-107): MNIST IDX files under --data-dir when present, never downloaded
+        return ddata.mnist_or_synthetic(cfg.data_dir, cfg.dataset_size, cfg.seed, log=_rank0_print, **gen)
     if kind == "imagenet":
         return ddata.SyntheticImageDataset(cfg.dataset_size, (3, 224, 224), classes, cfg.seed, **gen)
     if kind == "tiny_image":
@@ -129,12 +135,16 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
         if cfg.warmup_steps > 0 or cfg.cosine_steps > 0:
             total_steps = cfg.cosine_steps or (cfg.epochs * -(-steps_this_epoch // accum))
             sched = WarmupCosine(cfg.lr, cfg.warmup_steps, max(total_steps, cfg.warmup_steps + 1), cfg.min_lr)
+        want_overlap = cfg.opt_overlap == "on" or (cfg.opt_overlap == "auto" and getattr(model, "optimizer_overlap_pays", False))
         if (type(opt) is FusedSGD and graphed is None and sched is None and cfg.clip_grad_norm <= 0 and not cfg.sync_debug
-                and cfg.model.startswith("gpt2")):       # measured: +0.9 % GPT-2, -0.3 % ResNet-50 (HBM-bound throughout)
+                and want_overlap):                       # measured: +0.9 % GPT-2, -0.3 % ResNet-50 (HBM-bound throughout)
             # constant-lr SGD without clipping: every bucket is updated behind its all-reduce, during backward
             opt.overlap_with_backward(dp)
         guard = GCGuard(period=500)      # collector at a fixed step period, the same step on every rank (utils/gcguard.py)
         guard.__enter__()
+        # --breakdown: HIP events around forward / backward / dp.finish() (= the part of the gradient reduction that backward
+        # did NOT hide: "exposed communication") / optimizer; read back once per epoch, no host sync inside the step
+        phases = dmetrics.PhaseTimer(device, enabled=cfg.breakdown)
         for epoch in range(start_epoch, cfg.epochs):
             loader.set_epoch(epoch)
             epoch_loss = torch.zeros((), device=device)
@@ -143,9 +153,11 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                 if cfg.steps_per_epoch and step >= cfg.steps_per_epoch:
                     break
                 if graphed is not None and x.shape == graphed.static_inputs[0].shape:
-                    loss = graphed(x, y)
+                    with phases.phase("forward_backward_graph"):
+                        loss = graphed(x, y)
                     epoch_loss += loss.detach()
-                    dp.reduce_all()                      # no hook fires in a replay: the engine launches the bucket(s)
+                    with phases.phase("comm_exposed"):
+                        dp.reduce_all()                  # no hook fires in a replay: the engine launches the bucket(s)
                 elif accum > 1 and (step + 1) % accum != 0 and step + 1 < steps_this_epoch:
                     # gradient accumulation: local backward only, nothing on the wire until the last micro-step
                     with dp.no_sync():
@@ -156,10 +168,13 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                     guard.step()
                     continue
                 else:
-                    loss = loss_fn(model, x, y)
+                    with phases.phase("forward"):
+                        loss = loss_fn(model, x, y)
                     epoch_loss += loss.detach()          # stays on device: no host sync (DP.py:153)
-                    loss.backward()
-                    dp.finish()                          # bucketed all-reduce, overlapped with backward
+                    with phases.phase("backward"):
+                        loss.backward()
+                    with phases.phase("comm_exposed"):
+                        dp.finish()                      # bucketed all-reduce, overlapped with backward
                 if cfg.sync_debug and not cfg.shard_optimizer:   # (sharded: only the owner holds a shard's reduced gradient)
                     dmetrics.check_reduced_gradients(dp.flat, comm)
                 if cfg.clip_grad_norm > 0:
@@ -167,16 +182,22 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                     clip_grad_norm(dp.flat, cfg.clip_grad_norm, opt.grad_scale, shard, comm, optimizer=opt)
                 if sched is not None:
                     sched.apply(opt, opt.steps)
-                opt.step()                               # fused: scale, momentum, update, bf16 shadow, zero grad
+                with phases.phase("optimizer"):
+                    opt.step()                           # fused: scale, momentum, update, bf16 shadow, zero grad
                 meter.update(x.shape[0])
                 guard.step()
             last = float(epoch_loss / num_batches)
+            breakdown = {k + "_ms": round(v, 4) for k, v in phases.summary().items()} if cfg.breakdown else {}
             rate = meter.rate()
             print(dmetrics.epoch_line_dp(comm.rank, epoch, last), flush=True)            # DP.py:157
             total = comm.all_reduce_scalar(rate, "sum")
             if comm.rank == 0:
                 print(f"[dp] epoch {epoch}: {total:.1f} samples/s whole job ({rate:.1f}/rank, {meter.ms_per_step():.2f} ms/step)", flush=True)
-            log.log(kind="dp_epoch", epoch=epoch, loss=last, samples_per_sec=total, world_size=world_size)
+            if breakdown and comm.rank == 0:
+                print("[dp] epoch %d breakdown (mean ms/step): %s" % (epoch, ", ".join(f"{k[:-3]} {v:.3f}" for k, v in breakdown.items())), flush=True)
+            log.log(kind="dp_epoch", epoch=epoch, loss=last, samples_per_sec=total, world_size=world_size,
+                    ms_per_step=meter.ms_per_step(), allreduce_calls=dp.stats["allreduce_calls"],
+                    allreduce_bytes=dp.stats["allreduce_bytes"], **breakdown)
             if cfg.checkpoint:
                 save_checkpoint(cfg.checkpoint, model, opt, epoch, comm=comm)
         guard.__exit__(None, None, None)
@@ -218,14 +239,25 @@ def run_mp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                 raise ValueError("the MNIST model-parallel example has exactly 2 stages (Net1 | Net2)")
             layers = mnist.mnist_stages()                 # stage k on rank k (MP.py:118-124)
             stage_mod = layers[stage]
+            bounds = [(0, 1), (1, 2)]
             loss_fn = mnist.nll_loss
             kind, classes, use_lp = "mnist", 10, False
         else:
             full, kind, _, use_lp, classes = build_model(cfg.model, cfg.dropout)
             layers = full.pipeline_layers()
+            # a resumed run cuts the stages where the checkpointed run did: the split below comes from wall-clock
+            # measurements that differ from run to run, and optimizer state is stored per stage by stage-local index
+            saved_bounds = None
+            if cfg.resume:
+                from .checkpoint import peek_extra
+                ex = peek_extra(cfg.resume)
+                if ex.get("stage_bounds") is not None and int(ex.get("stages", -1)) == stages:
+                    saved_bounds = [tuple(int(v) for v in b) for b in ex["stage_bounds"]]
             # stages balanced by measured forward+backward TIME on the GPU (rank 0's measurement, so every rank cuts
             # at the same layers); by parameter count only where nothing can be timed (CPU)
-            if device.type == "cuda":
+            if saved_bounds is not None:
+                costs = None
+            elif device.type == "cuda":
                 from .parallel.pp import measure_costs
                 full = full.to(device).train()
                 mb = max(1, cfg.batch_size // max(1, cfg.micro_batches))
@@ -234,9 +266,22 @@ def run_mp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                 costs = measure_costs(layers, sample)
             else:
                 costs = param_costs(layers)
-            costs = active.broadcast_object(costs, src=0)
-            bounds = partition_balanced(costs, stages)
+            if saved_bounds is not None:
+                bounds = saved_bounds
+            else:
+                costs = active.broadcast_object(costs, src=0)
+                bounds = partition_balanced(costs, stages)
             stage_mod = build_stage_module(layers, bounds, stage, full)
+            if device.type == "cuda":
+                # the other stages' layers leave this GPU: only this stage's parameters stay resident
+                keep = {id(p) for p in stage_mod.parameters()} | {id(b) for b in stage_mod.buffers()}
+                for t in list(full.parameters()) + list(full.buffers()):
+                    if id(t) not in keep:
+                        t.data = torch.empty(0, dtype=t.dtype)
+            if dataset is None:
+                dataset = build_dataset(kind, cfg, classes, full, device)
+            del full, layers
+            full = None
             loss_fn = (lambda out, t: ops.softmax_cross_entropy(out.reshape(-1, out.shape[-1]), t.reshape(-1), classes))
         stage_mod = stage_mod.to(device).train()
         if dataset is None:
@@ -250,7 +295,8 @@ def run_mp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
         loader = ddata.BatchLoader(part, cfg.batch_size, shuffle=False, device=None if device.type == "cuda" else device)
         if device.type == "cuda":
             loader = ddata.PrefetchLoader(loader, device, workers=max(1, cfg.workers))
-        dp = DataParallel(stage_mod, dp_comm, use_lp=use_lp) if (dp_comm is not None) else None
+        dp = DataParallel(stage_mod, dp_comm, bucket_mb=cfg.bucket_mb, first_bucket_mb=cfg.first_bucket_mb,
+                          use_lp=use_lp) if (dp_comm is not None) else None
         flat = dp.flat if dp is not None else FlatParams(stage_mod, use_lp=use_lp)
         opt = FusedSGD(flat, lr=cfg.lr, momentum=cfg.momentum, weight_decay=cfg.weight_decay)   # one optimizer per stage
         if dp is not None:
@@ -263,19 +309,31 @@ def run_mp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
         log = dmetrics.JsonlLogger(cfg.log_json, global_rank, only_rank0=False)
         meter = dmetrics.ThroughputMeter(device)
         loss = None
+        phases = dmetrics.PhaseTimer(device, enabled=cfg.breakdown)
+        eng.timer = phases if cfg.breakdown else None          # forward / backward / p2p-wait per micro-batch (parallel/pp.py)
         for epoch in range(start_epoch, cfg.epochs):
             meter.reset(); meter.start()
             for step, (x, y) in enumerate(loader):
                 if cfg.steps_per_epoch and step >= cfg.steps_per_epoch:
                     break
-                loss = eng.train_step(x.shape[0], x if eng.first else None, y if eng.last else None)
-                opt.step()
+                with phases.phase("pipeline_step"):
+                    loss = eng.train_step(x.shape[0], x if eng.first else None, y if eng.last else None)
+                with phases.phase("optimizer"):
+                    opt.step()
                 meter.update(x.shape[0])
+            breakdown = {k + "_ms": round(v, 4) for k, v in phases.summary().items()} if cfg.breakdown else {}
+            if breakdown:
+                print("[mp] stage %d replica %d epoch %d breakdown (mean ms per occurrence): %s" % (
+                    stage, replica, epoch, ", ".join(f"{k[:-3]} {v:.3f}" for k, v in breakdown.items())), flush=True)
+                if not (eng.last and replica == 0):
+                    log.log(kind="mp_stage", epoch=epoch, stage=stage, replica=replica, **breakdown)
             if eng.last and replica == 0:
                 print(dmetrics.epoch_line_mp(epoch, loss), flush=True)                      # MP.py:169-170
-                log.log(kind="mp_epoch", epoch=epoch, loss=float(loss), samples_per_sec=meter.rate() * replicas)
+                log.log(kind="mp_epoch", epoch=epoch, loss=float(loss), samples_per_sec=meter.rate() * replicas,
+                        stage=stage, ms_per_step=meter.ms_per_step(), **breakdown)
             if cfg.checkpoint:
-                save_checkpoint(cfg.checkpoint, stage_mod, opt, epoch, comm=dp_comm, pipeline_comm=pp_comm)
+                save_checkpoint(cfg.checkpoint, stage_mod, opt, epoch, comm=dp_comm, pipeline_comm=pp_comm,
+                                extra={"stage_bounds": [list(b) for b in bounds], "stages": stages})
     except BaseException:
         raise                    # exit with the traceback; no barrier on the error path (see run_dp)
     active.barrier()

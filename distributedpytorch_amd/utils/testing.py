@@ -105,15 +105,24 @@ def dp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, buc
 
 
 def pp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, stages, replicas, n_micro, schedule, batch, steps,
-              share_gpu=False):
-    """Pipeline (x replicas) on gloo; writes per-stage grads after the first step and losses.
-    ``share_gpu``: every stage runs the HIP engine on GPU 0 (fused blocks with several micro-batches in flight,
-    gradient sinks accumulating over micro-batches, side stream), activations travel host-staged over gloo."""
+              share_gpu=False, backend="gloo", negotiate=True):
+    """Pipeline (x replicas); writes per-stage grads after the first step and losses.
+    ``backend`` "gloo": CPU tensors over gloo (the CPU tier).  ``share_gpu`` (or backend "gloo_gpu"): every stage runs
+    the HIP engine on GPU 0 (fused blocks with several micro-batches in flight, gradient sinks accumulating over
+    micro-batches, side stream), activations travel host-staged over gloo.  "nccl": one GPU per rank, activations and
+    gradients device to device over RCCL (multi-GPU boxes only; tests/test_multi_gpu.py) - the transport the pipeline
+    engine is built for (the reference stages through the host because gloo must, MP.py:139-145).
+    ``negotiate`` False: boundary shapes come from a local trace (``trace_shapes``), nothing is negotiated on the wire."""
     device = torch.device("cpu")
-    if share_gpu:
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    elif share_gpu or backend == "gloo_gpu":
+        share_gpu, backend = True, "gloo"
         torch.cuda.set_device(0)
         device = torch.device("cuda", 0)
-    world = dcomm.init_process_group("gloo", url, global_rank, world_size, 180.0 if share_gpu else 60.0, device)
+    on_gpu = device.type == "cuda"
+    world = dcomm.init_process_group(backend, url, global_rank, world_size, 180.0 if on_gpu else 60.0, device)
     pp_comm, dp_comm, replica, stage = dcomm.build_grid(world, replicas, stages)
     if stage >= 0:
         torch.manual_seed(1234)
@@ -141,20 +150,34 @@ def pp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, sta
             loss_fn, shape, classes = (lambda o, t: ops.softmax_cross_entropy(o, t, 16)), (3, 32, 32), 16
         x, y = _data(shape, classes, batch * replicas) if shape is not None else _tokens(batch * replicas)
         x, y = x[replica * batch:(replica + 1) * batch].to(device), y[replica * batch:(replica + 1) * batch].to(device)
+        in_meta = None
+        if not negotiate:
+            # boundary shapes without any wire traffic: the reference's split is known statically ([B, 320] fp32,
+            # MP.py:143,152); other models are traced locally on the CPU - every rank builds the same seeded model.
+            # (On a GPU the boundary is whatever the HIP engine emits - NHWC bf16 - which run_pipeline_bench gets from
+            # measure_costs; the test workers negotiate there.)
+            from ..parallel.pp import trace_shapes, stage_in_metas
+            if model_name == "mnist":
+                in_meta = [None, ((320,), torch.float32)][stage]
+            elif not on_gpu:
+                in_meta = stage_in_metas(trace_shapes(layers, x[:2]), bounds)[stage]
+            else:
+                negotiate = True
         stage_mod = stage_mod.to(device)
-        dp = DataParallel(stage_mod, dp_comm) if (replicas > 1 or share_gpu) else None
+        dp = DataParallel(stage_mod, dp_comm) if (replicas > 1 or on_gpu) else None
         flat = dp.flat if dp is not None else FlatParams(stage_mod)
         opt = FusedSGD(flat, lr=0.05, momentum=0.0)
         if dp is not None:
             opt.grad_scale = dp.grad_scale
-        eng = PipelineStage(stage_mod, pp_comm, loss_fn, n_micro=n_micro, schedule=schedule, dp=dp)
+        eng = PipelineStage(stage_mod, pp_comm, loss_fn, n_micro=n_micro, schedule=schedule, dp=dp,
+                            in_meta=in_meta, negotiate=negotiate)
         losses, slots = [], []
         for s in range(steps):
             loss = eng.train_step(batch, x if eng.first else None, y if eng.last else None)
             slots.append(eng._slots.allocated)
             if s == 0:
                 scale = opt.grad_scale if dp is not None else 1.0
-                if share_gpu:
+                if on_gpu:
                     torch.cuda.synchronize()
                 torch.save({n: (p.grad * scale).detach().cpu().clone() for n, p in stage_mod.named_parameters()},
                            os.path.join(out_dir, f"grads_r{replica}_s{stage}.pt"))

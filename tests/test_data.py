@@ -102,3 +102,57 @@ def test_prefetch_loader_same_batches_early_break_and_errors():
     next(it)
     with pytest.raises(RuntimeError, match="disk on fire"):
         next(it)
+
+
+def _write_idx(path, arr, gz=False):
+    """A tiny IDX file as the MNIST distribution lays it out: 0, 0, 0x08 (unsigned byte), rank; big-endian dims; bytes."""
+    import gzip
+    import struct
+    head = bytes([0, 0, 0x08, arr.dim()]) + struct.pack(">" + "I" * arr.dim(), *arr.shape)
+    opener = gzip.open if gz else open
+    with opener(path, "wb") as f:
+        f.write(head + arr.contiguous().numpy().tobytes())
+
+
+@pytest.mark.parametrize("layout,gz", [("", False), ("MNIST/raw", True)])
+def test_mnist_idx_reader_normalises_like_the_reference(tmp_path, layout, gz):
+    """data.MNISTIdx on a generated fixture (the reference reads torchvision's MNIST with ToTensor + Normalize((0.1307,),
+    (0.3081,)), multinode-DP/multinodeDP.py:100-107; no torchvision and no network here, so the files are the user's)."""
+    import os
+    from distributedpytorch_amd import data as D
+    g = torch.Generator().manual_seed(5)
+    imgs = torch.randint(0, 256, (37, 28, 28), generator=g, dtype=torch.uint8)
+    labs = torch.randint(0, 10, (37,), generator=g, dtype=torch.uint8)
+    root = tmp_path / layout
+    os.makedirs(root, exist_ok=True)
+    ext = ".gz" if gz else ""
+    _write_idx(str(root / f"train-images-idx3-ubyte{ext}"), imgs, gz)
+    _write_idx(str(root / f"train-labels-idx1-ubyte{ext}"), labs, gz)
+    ds = D.MNISTIdx(str(tmp_path))
+    assert len(ds) == 37 and ds.shape == (1, 28, 28)
+    x, y = ds[5]
+    want = (imgs[5].float() / 255.0 - 0.1307) / 0.3081
+    assert x.shape == (1, 28, 28) and y == int(labs[5]) and torch.allclose(x[0], want, atol=1e-6)
+    xb, yb = ds.batch([3, 36, 0])
+    assert xb.shape == (3, 1, 28, 28) and torch.equal(yb, labs[[3, 36, 0]].long())
+    assert torch.allclose(xb[1, 0], (imgs[36].float() / 255.0 - 0.1307) / 0.3081, atol=1e-6)
+    # the reference's partitioning + loader on top of it (DP.py:108-114): ragged last batch kept
+    loader, bsz = D.partition_dataset(ds, 0, 2, global_batch=8)
+    got = list(loader)
+    assert bsz == 4.0 and sum(b[0].shape[0] for b in got) == 18 and got[0][0].shape[1:] == (1, 28, 28)
+    # with the files absent the same entry point falls back to synthetic data of the same shape, and says so
+    said = []
+    assert isinstance(D.mnist_or_synthetic(str(tmp_path / "nowhere"), n=32, log=said.append), D.SyntheticImageDataset)
+    assert said and "synthetic" in said[0]
+    assert isinstance(D.mnist_or_synthetic(str(tmp_path), log=said.append), D.MNISTIdx)
+
+
+def test_mnist_idx_reader_refuses_what_is_not_idx(tmp_path):
+    from distributedpytorch_amd import data as D
+    (tmp_path / "train-images-idx3-ubyte").write_bytes(b"\x00\x00\x0d\x03" + b"\x00" * 64)     # float element type
+    (tmp_path / "train-labels-idx1-ubyte").write_bytes(b"\x00\x00\x08\x01\x00\x00\x00\x02\x01\x02")
+    with pytest.raises(ValueError, match="unsigned byte"):
+        D.MNISTIdx(str(tmp_path))
+    (tmp_path / "train-images-idx3-ubyte").write_bytes(b"\x00\x00\x08\x03" + b"\x00\x00\x00\x02" * 3 + b"\x01" * 5)
+    with pytest.raises(ValueError, match="truncated"):
+        D.MNISTIdx(str(tmp_path))

@@ -240,7 +240,8 @@ def test_tiny_resnet_trains_and_matches_cpu_first_step():
     losses, dp, opt = _train(m, x, y, 12)
     assert abs(losses[0] - lref) < 0.05, (losses[0], lref)          # bf16 forward vs fp32 CPU oracle
     assert losses[-1] < losses[0]
-    assert dp.stats["allreduce_calls"] >= 12
+    assert dp.stats["bucket_launches"] >= 12
+    assert dp.stats["allreduce_calls"] == 0 and dp.stats["allreduce_bytes"] == 0    # one process, no group: nothing was reduced
 
 
 def test_gpt2_tiny_trains_on_gpu():
@@ -381,8 +382,10 @@ def test_native_rccl_communicator_single_rank():
     want = dst + srcb[:, :1000].float().sum(0)
     outb = torch.empty(1000, dtype=torch.bfloat16, device=DEV)
     C.reduce_shards_bf16(dst, srcb.view(-1), 3, 1024, outb)
-    torch.testing.assert_close(dst, want)
     assert torch.equal(outb, want.to(torch.bfloat16))
+    # the owner keeps exactly what its peers will widen from the wire: replicas stay bit-identical
+    assert torch.equal(dst, outb.float())
+    torch.testing.assert_close(dst, want, rtol=8e-3, atol=1e-3)
 
 
 def test_native_rccl_layer_under_bucket_sized_traffic():

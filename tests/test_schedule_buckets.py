@@ -34,6 +34,44 @@ def test_1f1b_groups_send_with_recv():
     assert any(len(s) == 2 and s[0][0] == "send_bwd" and s[1][0] == "recv_fwd" for s in steps)
 
 
+@pytest.mark.parametrize("kind", ["serial", "gpipe", "1f1b"])
+def test_grouped_communication_is_deadlock_free_under_rendezvous_semantics(kind):
+    """ncclSend / ncclRecv are rendezvous operations on ONE in-order stream per rank (``validate`` models buffered
+    sends).  The groups the engine issues (``build_steps``) survive the strictest model - whole groups must pair up -
+    for every S in 2..8 and M in 1..16, and so also the model in which operations of a group complete one by one."""
+    for stages in range(2, 9):
+        for micro in range(1, 17):
+            S.validate_rendezvous(kind, stages, micro, strict=True)
+            S.validate_rendezvous(kind, stages, micro, strict=False)
+            for stage in range(stages):      # same operations in the same order as the plain schedule: only the grouping differs
+                flat = [op for g in S.build_steps(kind, stages, stage, micro) for op in g]
+                assert flat == S.build_schedule(kind, stages, stage, micro)
+
+
+def test_rendezvous_simulator_catches_the_groupings_it_is_there_to_catch():
+    # round 2's "maximal runs" grouping pairs a send to one neighbour with a receive from the other (and, in the serial
+    # schedule, a send with a receive the peer issues two groups apart): fine while operations of a group progress
+    # independently, a deadlock if whole groups had to pair up
+    steps = [S.group_comm(S.build_schedule("serial", 2, s, 1)) for s in range(2)]
+    S.validate_rendezvous("serial", 2, 1, strict=False, steps=steps)
+    with pytest.raises(AssertionError, match="rendezvous deadlock"):
+        S.validate_rendezvous("serial", 2, 1, strict=True, steps=steps)
+    # two neighbours that both send first, as separate calls: a deadlock under either model
+    bad = [[[("send_fwd", 0)], [("recv_bwd", 0)]], [[("send_bwd", 0)], [("recv_fwd", 0)]]]
+    for strict in (True, False):
+        with pytest.raises(AssertionError, match="rendezvous deadlock"):
+            S.validate_rendezvous("1f1b", 2, 1, strict=strict, steps=bad)
+    # 1F1B's steady-state exchange stays ONE group on both sides (both send first: it must be)
+    a = S.build_steps("1f1b", 4, 1, 8)
+    b = S.build_steps("1f1b", 4, 2, 8)
+    assert [("send_fwd", 2), ("recv_bwd", 0)] in a and [("send_bwd", 0), ("recv_fwd", 2)] in b
+    # ... and no group spans two peers
+    for st in range(4):
+        for g in S.build_steps("1f1b", 4, st, 8):
+            if g[0][0] in S.COMM_OPS:
+                assert len({S._peer_op(op, st)[0] for op in g}) == 1
+
+
 def test_partition_balanced():
     assert partition_balanced([1, 1, 1, 1], 2) == [(0, 2), (2, 4)]
     b = partition_balanced([10, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1], 2)

@@ -124,3 +124,73 @@ def test_clip_coefficient_folded_into_the_optimizer_equals_scaling_the_buffer():
             o.step()
         outs.append(f.master.clone())
     torch.testing.assert_close(outs[0], outs[1], rtol=1e-6, atol=1e-7)
+
+
+def test_breakdown_flag_writes_phase_times_to_the_jsonl(tmp_path):
+    """the TRAINING loops (not only bench.py) report forward / backward / exposed-communication / optimizer
+    milliseconds per step, and the counters of the reductions that were really issued."""
+    import json
+    from distributedpytorch_amd import train
+    url = f"tcp://127.0.0.1:{T.free_port()}"
+    logf = str(tmp_path / "dp.jsonl")
+    launch.spawn(train.run_dp, [2], 0, args=(_cfg(url, breakdown=True, log_json=logf, epochs=2),))
+    rows = [json.loads(l) for l in open(logf)]
+    assert len(rows) == 2 and rows[0]["kind"] == "dp_epoch"
+    for r in rows:
+        for k in ("forward_ms", "backward_ms", "comm_exposed_ms", "optimizer_ms", "ms_per_step"):
+            assert r[k] > 0.0, (k, r)
+        assert r["allreduce_calls"] >= 2 and r["allreduce_bytes"] > 0          # world 2: one bucket per step, really reduced
+    url = f"tcp://127.0.0.1:{T.free_port()}"
+    logm = str(tmp_path / "mp.jsonl")
+    launch.spawn(train.run_mp, [2], 0, args=(_cfg(url, stages=2, micro_batches=2, momentum=0.0, breakdown=True, log_json=logm),))
+    rows = [json.loads(l) for l in open(logm)]
+    kinds = {r["kind"] for r in rows}
+    assert kinds == {"mp_epoch", "mp_stage"}                                  # the last stage's epoch line + the other stage's times
+    for r in rows:
+        assert r["pipeline_step_ms"] > 0.0 and r["optimizer_ms"] > 0.0 and r["forward_ms"] > 0.0 and r["backward_ms"] > 0.0, r
+
+
+def _mp_with_fake_costs(local_rank, global_rank, world_size, cfg, shift):
+    """run_mp whose cost model is skewed by ``shift``: stands in for a wall-clock measurement that came out
+    differently on the resumed run."""
+    from distributedpytorch_amd import train
+    from distributedpytorch_amd.parallel import pp as ppmod
+    orig = ppmod.param_costs
+    train.param_costs = lambda layers: [c * (10.0 if i == shift else 1.0) for i, c in enumerate(orig(layers))]
+    train.run_mp(local_rank, global_rank, world_size, cfg)
+
+
+def test_pipeline_resume_cuts_the_stages_where_the_checkpoint_did(tmp_path):
+    """the stage split comes from measurements that vary between runs, optimizer state is stored per
+    stage by stage-local index - so the bounds travel in the checkpoint and a resumed run reuses them."""
+    ck = str(tmp_path / "pp.pt")
+    kw = dict(model="tiny_resnet", stages=2, micro_batches=2, momentum=0.9, batch_size=8, dataset_size=16, checkpoint=ck)
+    launch.spawn(_mp_with_fake_costs, [2], 0, args=(_cfg(f"tcp://127.0.0.1:{T.free_port()}", epochs=1, **kw), 0))
+    p1 = torch.load(ck, weights_only=True)
+    b1 = p1["extra"]["stage_bounds"]
+    assert p1["extra"]["stages"] == 2 and b1[0][0] == 0 and b1[0][1] == b1[1][0]
+    # the resumed run's own cost model would cut elsewhere ...
+    launch.spawn(_mp_with_fake_costs, [2], 0, args=(_cfg(f"tcp://127.0.0.1:{T.free_port()}", epochs=1, **dict(kw, checkpoint=str(tmp_path / "other.pt"))), 2))
+    assert torch.load(tmp_path / "other.pt", weights_only=True)["extra"]["stage_bounds"] != b1
+    # ... but with --resume it keeps the checkpoint's, and the per-stage momentum lands on the parameters it belongs to
+    launch.spawn(_mp_with_fake_costs, [2], 0, args=(_cfg(f"tcp://127.0.0.1:{T.free_port()}", epochs=2, resume=ck, **kw), 2))
+    p2 = torch.load(ck, weights_only=True)
+    assert p2["extra"]["stage_bounds"] == b1 and p2["epoch"] == 1
+    assert p2["optimizer"][0]["steps"] == 2 * p1["optimizer"][0]["steps"]
+
+
+def test_gpt2_pipeline_checkpoint_with_a_bare_embedding_stage_keeps_the_dropout_streams(tmp_path):
+    """a stage that is ONE bare layer (gpt2_tiny over 4 stages: the Embedding) exposes GPT-2's
+    per-module dropout call counter as ``module._drop``; the checkpoint writer handled only the MNIST nets' step
+    counter there.  All stages' dropout positions are saved and restored."""
+    ck = str(tmp_path / "g.pt")
+    kw = dict(model="gpt2_tiny", stages=4, micro_batches=2, momentum=0.0, batch_size=4, dataset_size=8, dropout=0.1,
+              checkpoint=ck, lr=0.01)
+    from distributedpytorch_amd import train
+    launch.spawn(train.run_mp, [4], 0, args=(_cfg(f"tcp://127.0.0.1:{T.free_port()}", epochs=1, **kw),))
+    p = torch.load(ck, weights_only=True)
+    calls = p["dropout_calls"]
+    assert len(calls) >= 3 and all(v > 0 for v in calls.values()), calls      # embedding + attention / MLP sites of every block
+    launch.spawn(train.run_mp, [4], 0, args=(_cfg(f"tcp://127.0.0.1:{T.free_port()}", epochs=2, resume=ck, **kw),))
+    p2 = torch.load(ck, weights_only=True)
+    assert p2["epoch"] == 1 and all(p2["dropout_calls"][k] == 2 * v for k, v in calls.items()), (calls, p2["dropout_calls"])
