@@ -23,3 +23,13 @@ DPA_FORCE_COLLECTIVES=1 timeout -k 10 240 python -m torch.distributed.run --nnod
     --master-port $((29500 + RANDOM % 400)) bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/rehearse/rccl1_r50.log 2>&1 || { tail -15 gpurun_out/rehearse/rccl1_r50.log; exit 1; }
 echo "rccl1_r50 $(grep '^{' gpurun_out/rehearse/rccl1_r50.log | tail -1 | cut -c1-150)"
 grep -o '"comm_layer": "[^"]*"' gpurun_out/rehearse/rccl1_r50.log | tail -1
+# one RCCL world communicator per process: with the native layer attached c10d is a gloo control plane, so the RCCL log
+# shows ONE communicator initialisation (round 2 had two: c10d's ProcessGroupNCCL beside the native one)
+DPA_FORCE_COLLECTIVES=1 NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT timeout -k 10 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 \
+    --master-port $((29500 + RANDOM % 400)) bench.py --gpus 1 --model tiny_resnet --batch 32 --steps 5 --warmup 2 > gpurun_out/rehearse/rccl1_init.log 2>&1 || { tail -15 gpurun_out/rehearse/rccl1_init.log; exit 1; }
+echo "rccl1_init: $(grep -c 'Init COMPLETE\|ncclCommInitRank.*COMPLETE\|Init START' gpurun_out/rehearse/rccl1_init.log) RCCL init lines; $(grep -o '"comm_layer": "[^"]*"' gpurun_out/rehearse/rccl1_init.log | tail -1)"
+grep -i 'init complete\|init start\|commInitRank' gpurun_out/rehearse/rccl1_init.log | cut -c1-160 | head -6
+# the fallback: the native self-test fails on purpose, every rank adopts a c10d RCCL group instead
+DPA_FORCE_COLLECTIVES=1 DPA_COMM_SELFTEST_TIMEOUT=0 timeout -k 10 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 \
+    --master-port $((29500 + RANDOM % 400)) bench.py --gpus 1 --model tiny_resnet --batch 32 --steps 5 --warmup 2 > gpurun_out/rehearse/rccl1_fallback.log 2>&1 || { tail -15 gpurun_out/rehearse/rccl1_fallback.log; exit 1; }
+echo "rccl1_fallback: $(grep -o '"comm_layer": "[^"]*"' gpurun_out/rehearse/rccl1_fallback.log | tail -1) $(grep -c 'falling back to c10d' gpurun_out/rehearse/rccl1_fallback.log) fallback notice(s)"

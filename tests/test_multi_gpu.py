@@ -121,3 +121,163 @@ def test_native_group_without_torch_distributed(tmp_path):
     launch.spawn(_native_group_worker, [world], 0, args=(url, str(tmp_path)))
     for r in range(world):
         assert (tmp_path / f"native_{r}.pt").exists()
+
+
+# ------------------------------------------------------------------------------------------------ pipelines over RCCL
+# BASELINE configs 2 and 4: stage k on GPU k, activations / gradients device to device by ncclSend / ncclRecv through
+# the native communicator's batch_p2p (reference: multinode-MP/multinodeMP.py:118-167, which stages through the host).
+# The same assertions as tests/test_pp_gloo.py (losses and per-stage gradients equal the unsplit CPU model fed the
+# same micro-batches), with bf16-engine tolerances where the stage runs the HIP ResNet blocks.
+
+def _pp_reference(model_name, batch, n_micro, replicas=1):
+    import test_pp_gloo as P
+    return [P._reference(model_name, batch, n_micro, r, replicas) for r in range(replicas)]
+
+
+def _check_pp(tmp_path, model_name, stages, replicas, n_micro, batch, exact):
+    from distributedpytorch_amd.parallel.pp import partition_balanced, param_costs
+    refs = _pp_reference(model_name, batch, n_micro, replicas)
+    layers0 = refs[0][0]
+    bounds = [(0, 1), (1, 2)] if model_name == "mnist" else partition_balanced(param_costs(layers0), stages)
+    final = torch.load(tmp_path / f"final_r0_s{stages - 1}.pt", weights_only=True)
+    ref_loss = refs[0][1]
+    assert abs(final["losses"][0] - ref_loss) < (1e-4 if exact else 0.05) * max(1.0, abs(ref_loss)), (final["losses"], ref_loss)
+    assert final["losses"][-1] < final["losses"][0]
+    num = den = 0.0
+    for s in range(stages):
+        a, b = bounds[s]
+        got = torch.load(tmp_path / f"grads_r0_s{s}.pt", weights_only=True)
+        for li in range(a, b):
+            for n, p in layers0[li].named_parameters():
+                key = n if b - a == 1 else f"{li - a}.{n}"
+                g = sum(dict(refs[r][0][li].named_parameters())[n].grad for r in range(replicas)) / replicas
+                if exact:
+                    assert torch.allclose(got[key], g, rtol=2e-3, atol=2e-5), f"stage {s} grad {key}"
+                elif got[key].shape == g.shape:
+                    num += float(((got[key] - g) ** 2).sum()); den += float((g ** 2).sum())
+    if not exact:
+        assert num <= 0.25 ** 2 * den, (num, den)     # bf16 engine against the fp32 oracle, in aggregate
+    return final
+
+
+@pytest.mark.parametrize("native", [True, False])
+@pytest.mark.parametrize("schedule,n_micro,batch", [("serial", 1, 16), ("1f1b", 4, 12)])
+def test_two_stage_mnist_pipeline_over_rccl(tmp_path, monkeypatch, native, schedule, n_micro, batch):
+    """BASELINE config 2: Net1 | Net2 on two GPUs, [B, 320] activations and gradients over RCCL send/recv (no shape
+    negotiation: both ranks know the boundary, as in the reference), ragged batch 12 / 4 micro-batches included."""
+    _need(2)
+    monkeypatch.setenv("DPA_COMM", "native" if native else "c10d")
+    url = f"tcp://127.0.0.1:{T.free_port()}"
+    launch.spawn(T.pp_worker, [2], 0, args=(url, "mnist", str(tmp_path), 2, 1, n_micro, schedule, batch, 3, False, "nccl", False))
+    _check_pp(tmp_path, "mnist", 2, 1, n_micro, batch, exact=True)
+
+
+@pytest.mark.parametrize("schedule", ["1f1b", "gpipe"])
+def test_four_stage_resnet_pipeline_over_rccl(tmp_path, schedule):
+    """BASELINE config 4 in miniature: tiny ResNet over 4 GPUs, 8 micro-batches, HIP engine on every stage."""
+    _need(4)
+    url = f"tcp://127.0.0.1:{T.free_port()}"
+    launch.spawn(T.pp_worker, [4], 0, args=(url, "tiny_resnet", str(tmp_path), 4, 1, 8, schedule, 32, 3, False, "nccl"))
+    final = _check_pp(tmp_path, "tiny_resnet", 4, 1, 8, 32, exact=False)
+    assert final["slots"][-1] == final["slots"][0]           # receive slots stop being allocated after the first step
+
+
+def test_dp_x_pp_grid_over_rccl(tmp_path):
+    """2 pipeline replicas x 2 stages on 4 GPUs: ncclCommSplit sub-communicators (pipeline group per replica,
+    data-parallel group per stage), stage gradients averaged across the replicas."""
+    _need(4)
+    url = f"tcp://127.0.0.1:{T.free_port()}"
+    launch.spawn(T.pp_worker, [4], 0, args=(url, "mnist", str(tmp_path), 2, 2, 4, "1f1b", 16, 3, False, "nccl"))
+    _check_pp(tmp_path, "mnist", 2, 2, 4, 16, exact=True)
+    g0 = torch.load(tmp_path / "grads_r0_s0.pt", weights_only=True)
+    g1 = torch.load(tmp_path / "grads_r1_s0.pt", weights_only=True)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), f"replicas disagree on the reduced gradient of {k}"
+
+
+def test_gpt2_pipeline_over_rccl_keeps_the_tied_embedding_in_step(tmp_path):
+    """GPT-2's wte sits on the first stage (embedding) and on the last (LM head): its two gradients are summed through
+    the pipeline group every step (bf16 on the wire, fp32 accumulate) and both copies stay bit-identical."""
+    _need(2)
+    from distributedpytorch_amd.ops import _ext
+    if not hasattr(_ext.load(), "attention_fwd"):
+        pytest.skip("attention kernels not built")
+    url = f"tcp://127.0.0.1:{T.free_port()}"
+    launch.spawn(T.pp_worker, [2], 0, args=(url, "gpt2_tiny", str(tmp_path), 2, 1, 2, "1f1b", 4, 3, False, "nccl"))
+    final = torch.load(tmp_path / "final_r0_s1.pt", weights_only=True)
+    assert final["losses"][-1] < final["losses"][0]
+    ck = torch.load(tmp_path / "ckpt_r0.pt", weights_only=True)
+    g_first = torch.load(tmp_path / "grads_r0_s0.pt", weights_only=True)
+    g_last = torch.load(tmp_path / "grads_r0_s1.pt", weights_only=True)
+    tied_first = [k for k in g_first if k.endswith("wte")]
+    tied_last = [k for k in g_last if k.endswith("wte")]
+    assert tied_first and tied_last and "model" in ck
+    assert torch.equal(g_first[tied_first[0]], g_last[tied_last[0]])      # both ends hold the SAME summed gradient
+
+
+def test_zero1_sharded_optimizer_over_rccl(tmp_path):
+    """ZeRO stage 1 over RCCL: bucket pieces reduced onto their owners, owner-only SGD, parameters broadcast back;
+    replicas stay bit-identical and match the replicated optimizer's result."""
+    _need(2)
+    world = min(4, torch.cuda.device_count())
+    res = {}
+    for mode in ("zero", "hooks"):
+        out = tmp_path / mode
+        out.mkdir()
+        url = f"tcp://127.0.0.1:{T.free_port()}"
+        launch.spawn(T.dp_worker, [world], 0, args=(url, "mnist", str(out), 16, 3, mode, "nccl"))
+        res[mode] = [torch.load(out / f"final_{r}.pt", weights_only=True) for r in range(world)]
+        for r in range(1, world):
+            for name in res[mode][0]["params"]:
+                assert torch.equal(res[mode][0]["params"][name], res[mode][r]["params"][name]), f"{mode}: replicas diverged at {name}"
+    for name, p in res["hooks"][0]["params"].items():
+        assert torch.allclose(res["zero"][0]["params"][name], p, rtol=1e-4, atol=1e-6), name
+    assert res["zero"][0]["momentum_numel"] < res["hooks"][0]["momentum_numel"]
+
+
+def test_native_selftest_failure_falls_back_to_c10d_rccl(tmp_path, monkeypatch):
+    """DPA_COMM_SELFTEST_TIMEOUT=0 makes the native layer's self-test fail on every rank: all of them agree (over the
+    gloo control plane) to adopt a c10d RCCL group instead, and data-parallel training still matches the reference."""
+    _need(2)
+    monkeypatch.setenv("DPA_COMM", "native")
+    monkeypatch.setenv("DPA_COMM_SELFTEST_TIMEOUT", "0")
+    url = f"tcp://127.0.0.1:{T.free_port()}"
+    launch.spawn(T.dp_worker, [2], 0, args=(url, "mnist", str(tmp_path), 1024, 3, "hooks", "nccl"))
+    ref = _cpu_reference_mean_grads(2)
+    got = torch.load(tmp_path / "grads_0.pt", weights_only=True)
+    for name, g in ref.items():
+        assert torch.allclose(got[name], g, rtol=1e-3, atol=1e-5), name
+
+
+def _torchrun_bench(n, extra, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                          "--master-addr", "127.0.0.1", "--master-port", str(T.free_port()), os.path.join(root, "bench.py"),
+                          "--gpus", str(n)] + extra, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_pipeline_mnist_two_stages():
+    """``bench.py --pipeline 2 --model mnist`` (BASELINE config 2) under torchrun prints the driver's JSON line."""
+    _need(2)
+    rec = _torchrun_bench(2, ["--pipeline", "2", "--model", "mnist", "--steps", "5", "--warmup", "2"])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["parallelism"] == "pp2xdp1"
+    pipe = rec["config"]["pipeline"]
+    assert len(pipe["stages"]) == 2 and pipe["peak_live_microbatches"][0] >= pipe["peak_live_microbatches"][1]
+    assert all(st["busy_ms_per_step"] > 0 for st in pipe["stages"])
+
+
+def test_bench_pipeline_resnet152_four_stages():
+    """``bench.py --pipeline 4 --model resnet152`` (BASELINE config 4; x 2 replicas on 8 GPUs) under torchrun."""
+    _need(4)
+    n = 8 if torch.cuda.device_count() >= 8 else 4
+    rec = _torchrun_bench(n, ["--pipeline", "4", "--model", "resnet152", "--batch", "64", "--micro-batches", "4",
+                              "--steps", "3", "--warmup", "1"], timeout=900)
+    assert rec["n_gpus"] == n and rec["value"] > 0 and rec["config"]["parallelism"] == f"pp4xdp{n // 4}"
+    pipe = rec["config"]["pipeline"]
+    assert len(pipe["stages"]) == 4 and 0.0 <= pipe["bubble_fraction_theory"] < 1.0
+    assert all(st["max_memory_allocated_gb"] < 288 for st in pipe["stages"])
