@@ -5,6 +5,7 @@
 #include <torch/extension.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/hip/HIPCachingAllocator.h>
 
 #include "kernels.h"
 
@@ -1020,8 +1021,16 @@ Tensor mul_f32(const Tensor& a, const Tensor& b) {
 void bind_transformer(pybind11::module_& m);  // bindings_tfm.cpp
 void bind_rccl(pybind11::module_& m);         // rccl_comm.cpp
 
+// Launcher temporaries (gemm_wide's split-K slabs) come from torch's caching allocator: visible to torch.cuda.memory_*,
+// shared with the step's other temporaries, re-issued only to later work of the stream they were taken for.
+static void* torch_workspace_alloc(size_t bytes, hipStream_t stream) {
+    return c10::hip::HIPCachingAllocator::raw_alloc_with_stream(bytes, stream);
+}
+static void torch_workspace_free(void* ptr) { c10::hip::HIPCachingAllocator::raw_delete(ptr); }
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "distributedpytorch_amd gfx950 kernels";
+    dpa::set_workspace_allocator(&torch_workspace_alloc, &torch_workspace_free);
     m.def("conv_fprop", &conv_fprop, py::arg("x"), py::arg("w"), py::arg("bias"), py::arg("stride"), py::arg("pad"), py::arg("act"),
           py::arg("want_stats"), py::arg("stats_buf"), py::arg("addend") = py::none(), py::arg("gelu_twin") = false,
           py::arg("stride_w") = -1, py::arg("pad_w") = -1, py::arg("out_w") = -1);
@@ -1088,6 +1097,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("nll_bwd", &nll_bwd);
     m.def("dropout_mask", &dropout_mask);
     m.def("counter_add", &counter_add);
+    m.def("axpy_dev", [](Tensor& dst, const Tensor& src, const Tensor& g) {
+        CHECK_F32(dst); CHECK_F32(src); CHECK_F32(g);
+        TORCH_CHECK(src.numel() == dst.numel() && g.numel() == 1, "axpy_dev: sizes");
+        Guard gd(dst);
+        dpa::axpy_dev(dst.data_ptr<float>(), src.data_ptr<float>(), dst.numel(), g.data_ptr<float>(), cur_stream());
+    });
     m.def("reduce_shards", [](Tensor& dst, const Tensor& src, int64_t nsrc, int64_t stride) {
         CHECK_F32(dst); CHECK_F32(src);
         TORCH_CHECK(src.numel() >= (nsrc - 1) * stride + dst.numel(), "reduce_shards: src too small");

@@ -498,6 +498,28 @@ void reduce_shards_bf16(float* dst, const void* src, int nsrc, long stride, long
                        stride, n, (unsigned short*)out);
 }
 
+// dst[i] += (*g) * src[i]   (fp32; the upstream gradient stays on the device: no host read to test it against 1)
+__global__ __launch_bounds__(256) void axpy_dev_kernel(float* __restrict__ dst, const float* __restrict__ src, long n,
+                                                       const float* __restrict__ g) {
+    const float a = *g;
+    const long n4 = n / 4;
+    const bool vec = ((uintptr_t)dst % 16 == 0) && ((uintptr_t)src % 16 == 0);
+    if (vec) {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+            float4 d = ((const float4*)dst)[i];
+            const float4 v = ((const float4*)src)[i];
+            d.x += a * v.x; d.y += a * v.y; d.z += a * v.z; d.w += a * v.w;
+            ((float4*)dst)[i] = d;
+        }
+    }
+    for (long i = (vec ? n4 * 4 : 0) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        dst[i] += a * src[i];
+}
+
+void axpy_dev(float* dst, const float* src, long n, const float* g, hipStream_t st) {
+    hipLaunchKernelGGL(axpy_dev_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, dst, src, n, g);
+}
+
 __global__ void counter_add_kernel(int64_t* c, int64_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += v; }
 
 void counter_add(int64_t* c, int64_t v, hipStream_t st) { hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, st, c, v); }

@@ -432,12 +432,26 @@ __global__ __launch_bounds__(256) void gemm_splitk_fold_kernel(ConvArgs a, const
 int g_wide_min_tiles = -1;      // -1: not yet read from the environment
 int g_wide_splitk = -1;         // -1: not yet read; 0 = choose per launch; n > 0 = force
 
-// grow-only fp32 workspace per stream (two streams may run split-K GEMMs side by side)
+// Split-K workspace.  With an allocator registered (bindings.cpp hands in torch's caching allocator), every split-K launch
+// takes a block for the launch's stream and gives it back right after the fold kernel has been enqueued: the caching
+// allocator only re-issues it to later work of the same stream, so the memory is visible to torch.cuda.memory_*, shared
+// with every other temporary of the step, and never held while idle.  Without one (stand-alone harnesses): a grow-only
+// block per stream from hipMalloc.
+WorkspaceAlloc g_ws_alloc = nullptr;
+WorkspaceFree g_ws_free = nullptr;
 struct Workspace { float* ptr = nullptr; size_t bytes = 0; };
 std::mutex g_ws_mutex;
 std::unordered_map<hipStream_t, Workspace> g_ws;
 
 float* workspace_for(hipStream_t st, size_t bytes) {
+    if (g_ws_alloc != nullptr) {
+        float* p = (float*)g_ws_alloc(bytes, st);
+        if (p == nullptr) {
+            fprintf(stderr, "gemm_wide: the registered allocator returned no %zu-byte split-K workspace\n", bytes);
+            abort();
+        }
+        return p;
+    }
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     Workspace& w = g_ws[st];
     if (w.bytes < bytes) {
@@ -572,7 +586,13 @@ void gemm_wide(const ConvArgs& a, hipStream_t st) {
         long blocks = (MN / 8 + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(gemm_splitk_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, (const float*)g.ws, g.splitk, MN, a.K);
+        if (g_ws_alloc != nullptr && g_ws_free != nullptr) g_ws_free(g.ws);      // stream-ordered: reusable behind the fold
     }
+}
+
+void set_workspace_allocator(WorkspaceAlloc alloc, WorkspaceFree free_) {
+    g_ws_alloc = alloc;
+    g_ws_free = free_;
 }
 
 }  // namespace dpa

@@ -61,6 +61,11 @@ void gemm_wide(const ConvArgs& a, hipStream_t st);
 void set_wide_gemm_min_tiles(int n);
 void set_wide_gemm_splitk(int n);   // 0 = chosen per launch by a cost model, n > 0 = forced (tests)
 int wide_gemm_min_tiles();
+// Temporary device memory of the kernels' launchers (gemm_wide's split-K slabs): alloc(bytes, stream) returns a block that
+// may be used by work enqueued on `stream` until free(ptr); the framework registers torch's caching allocator
+typedef void* (*WorkspaceAlloc)(size_t bytes, hipStream_t stream);
+typedef void (*WorkspaceFree)(void* ptr);
+void set_workspace_allocator(WorkspaceAlloc alloc, WorkspaceFree free_);
 
 // wgrad: dw[k,r,s,c] += sum_{n,ho,wo} dy[n,ho,wo,k] * x[n, ho*stride-pad+r, wo*stride-pad+s, c]
 // dw is fp32 and is accumulated into with float atomics (split over the pixel axis).
@@ -251,6 +256,8 @@ void counter_add(int64_t* c, int64_t v, hipStream_t st);
 // dst[i] += sum_{k<nsrc} src[k*stride + i], i < n (fp32; local step of the direct all-reduce)
 void reduce_shards(float* dst, const float* src, int nsrc, long stride, long n, hipStream_t st);   // device-resident step counter (graph-replay safe)
 void mul_f32(const float* a, const float* b, float* y, long n, hipStream_t st);
+// dst[i] += (*g) * src[i], g a device scalar
+void axpy_dev(float* dst, const float* src, long n, const float* g, hipStream_t st);
 // dst[i] += sum_{k<nsrc} bf16 src[k*stride + i] in fp32; out[i] = bf16(dst[i])  (bf16 wire format of the direct all-reduce)
 void reduce_shards_bf16(float* dst, const void* src, int nsrc, long stride, long n, void* out, hipStream_t st);
 

@@ -149,12 +149,47 @@ __device__ __forceinline__ uint4 ld16(const unsigned short* p) {
     return *(const uint4*)p;
 }
 
-template <bool RELU, bool RES, bool INV, bool NT, bool NTR = false>
+__device__ __forceinline__ void st16(unsigned short* p, const uint4& v, int nts) {
+    if (nts) __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, (u32x4*)p);
+    else *(uint4*)p = v;
+}
+
+// Walk of the streaming kernels.  A thread's local chunk index inside its region is j = off0 + it * sweep + u * 256
+// (u < U: U chunks per iteration, ALL their loads issued before the first use - one 16-byte load per thread in flight
+// was the limit of these passes: 4.2-5.3 TB/s where four reach 5.9-6.2, scripts/stream_probe.hip), the region is the
+// whole tensor (rev = 0) or the eighth that workgroup b & 7 owns, walked DESCENDING (rev; see bn_apply_kernel).
+struct StreamWalk {
+    long base, sweep, R;      // global chunk of local index 0 (rev: the region's LAST chunk), chunks per sweep, region size
+    long off0;
+    int dir, ch0;
+};
+template <int U>
+__device__ __forceinline__ StreamWalk stream_walk(long nchunks, int cpr, int rev) {
+    StreamWalk w;
+    if (rev) {
+        w.R = nchunks >> 3;
+        w.sweep = (long)(gridDim.x >> 3) * 256 * U;
+        w.off0 = (long)(blockIdx.x >> 3) * 256 * U + threadIdx.x;
+        w.base = (long)((blockIdx.x & 7) + 1) * w.R - 1;
+        w.dir = -1;
+        w.ch0 = cpr - 1 - (int)(threadIdx.x % cpr);
+    } else {
+        w.R = nchunks;
+        w.sweep = (long)gridDim.x * 256 * U;
+        w.off0 = (long)blockIdx.x * 256 * U + threadIdx.x;
+        w.base = 0;
+        w.dir = 1;
+        w.ch0 = threadIdx.x % cpr;
+    }
+    return w;
+}
+
+template <bool RELU, bool RES, bool INV, bool NT, bool NTR = false, int U = 1>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ res,
                                                        unsigned short* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, unsigned char* __restrict__ mask,
                                                        long nchunks, int cpr, const float* __restrict__ rscale,
-                                                       const float* __restrict__ rshift, int rev) {
+                                                       const float* __restrict__ rshift, int rev, int nts) {
     constexpr bool inv = INV;
     const bool rproj = RES && rscale != nullptr;   // the residual is itself a raw conv output behind its own BatchNorm (projection shortcut)
     // rev (INV only; host: gridDim.x % 8 == 0, nchunks % 2048 == 0): walk the tensor the way the producing convolution
@@ -162,58 +197,55 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
     // mod 8) one contiguous eighth of the pixel tiles, ascending, so the most recently written bytes are the ENDS of the
     // eight ranges; this kernel's workgroup b takes eighth b & 7 and walks it DESCENDING, and so finishes at the heads
     // of the ranges, where the next convolution starts.
-    long i0, step, count;
-    int ch0;
-    if (inv && rev) {
-        const long R = nchunks >> 3, GB = (long)(gridDim.x >> 3) * 256;
-        const long off0 = (long)(blockIdx.x >> 3) * 256 + threadIdx.x;
-        i0 = (long)((blockIdx.x & 7) + 1) * R - 1 - off0;
-        step = -GB;
-        count = off0 < R ? (R - off0 + GB - 1) / GB : 0;
-        ch0 = cpr - 1 - (int)(threadIdx.x % cpr);
-    } else {
-        const long S = (long)gridDim.x * 256;
-        i0 = (long)blockIdx.x * 256 + threadIdx.x;
-        step = S;
-        count = i0 < nchunks ? (nchunks - i0 + S - 1) / S : 0;
-        ch0 = threadIdx.x % cpr;
-    }
+    const StreamWalk w = stream_walk<U>(nchunks, cpr, inv && rev);
     float sc[8], sh[8], rs[8], rb[8];
     if (inv) {
-        load8(scale, ch0, sc); load8(shift, ch0, sh);
-        if (rproj) { load8(rscale, ch0, rs); load8(rshift, ch0, rb); }
+        load8(scale, w.ch0, sc); load8(shift, w.ch0, sh);
+        if (rproj) { load8(rscale, w.ch0, rs); load8(rshift, w.ch0, rb); }
     }
-    long i = i0;
-    for (long it = 0; it < count; ++it, i += step) {
-        uint4 v = ld16<NT>(x + i * 8);          // NT: the raw conv output is not read again before backward
-        uint4 rv;
-        if (RES) rv = ld16<NTR>(res + i * 8);
-        if (!inv) {
-            const int ch = (int)(i % cpr);
-            load8(scale, ch, sc); load8(shift, ch, sh);
-            if (rproj) { load8(rscale, ch, rs); load8(rshift, ch, rb); }
-        }
-        float f[8]; unpack8(v, f);
-        float r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (RES) {
-            unpack8(rv, r);
-            if (rproj) {
+    for (long j0 = w.off0; j0 < w.R; j0 += w.sweep) {
+        uint4 v[U], rv[U];
+        long idx[U];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) r[j] = r[j] * rs[j] + rb[j];
+        for (int u = 0; u < U; ++u) {
+            const long j = j0 + u * 256;
+            idx[u] = j < w.R ? w.base + w.dir * j : -1;
+            if (idx[u] >= 0) {
+                v[u] = ld16<NT>(x + idx[u] * 8);          // NT: the raw conv output is not read again before backward
+                if (RES) rv[u] = ld16<NTR>(res + idx[u] * 8);
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float t = f[j] * sc[j] + sh[j] + r[j];
-            if (RELU) t = fmaxf(t, 0.f);
-            f[j] = t;
-        }
-        *(uint4*)(y + i * 8) = pack8(f);
-        if (RELU && mask != nullptr) {      // one bit per element: the backward pass reads 1/16 of the bytes of y
-            unsigned m = 0;
+        for (int u = 0; u < U; ++u) {
+            const long i = idx[u];
+            if (i < 0) continue;
+            if (!inv) {
+                const int ch = (int)(i % cpr);
+                load8(scale, ch, sc); load8(shift, ch, sh);
+                if (rproj) { load8(rscale, ch, rs); load8(rshift, ch, rb); }
+            }
+            float f[8]; unpack8(v[u], f);
+            float r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (RES) {
+                unpack8(rv[u], r);
+                if (rproj) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) m |= (f[j] > 0.f ? 1u : 0u) << j;
-            mask[i] = (unsigned char)m;
+                    for (int k = 0; k < 8; ++k) r[k] = r[k] * rs[k] + rb[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float t = f[k] * sc[k] + sh[k] + r[k];
+                if (RELU) t = fmaxf(t, 0.f);
+                f[k] = t;
+            }
+            st16(y + i * 8, pack8(f), nts);
+            if (RELU && mask != nullptr) {      // one bit per element: the backward pass reads 1/16 of the bytes of y
+                unsigned m = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m |= (f[k] > 0.f ? 1u : 0u) << k;
+                mask[i] = (unsigned char)m;
+            }
         }
     }
 }
@@ -272,50 +304,50 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
     }
 }
 
-template <bool RELU, bool INV, bool NT>
+template <bool RELU, bool INV, bool NT, int U = 1>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* __restrict__ dy, const unsigned char* __restrict__ mask,
                                                            const unsigned short* __restrict__ x, const float* __restrict__ cA,
                                                            const float* __restrict__ cB, const float* __restrict__ cC,
-                                                           unsigned short* __restrict__ dx, long nchunks, int cpr, int rev) {
+                                                           unsigned short* __restrict__ dx, long nchunks, int cpr, int rev, int nts) {
     constexpr bool inv = INV;                      // coefficients loaded once per thread (see bn_apply_kernel)
-    long i0, step, count;                          // rev: each XCD's eighth of the tensor, descending (see bn_apply_kernel)
-    int ch0;
-    if (inv && rev) {
-        const long R = nchunks >> 3, GB = (long)(gridDim.x >> 3) * 256;
-        const long off0 = (long)(blockIdx.x >> 3) * 256 + threadIdx.x;
-        i0 = (long)((blockIdx.x & 7) + 1) * R - 1 - off0;
-        step = -GB;
-        count = off0 < R ? (R - off0 + GB - 1) / GB : 0;
-        ch0 = cpr - 1 - (int)(threadIdx.x % cpr);
-    } else {
-        const long S = (long)gridDim.x * 256;
-        i0 = (long)blockIdx.x * 256 + threadIdx.x;
-        step = S;
-        count = i0 < nchunks ? (nchunks - i0 + S - 1) / S : 0;
-        ch0 = threadIdx.x % cpr;
-    }
+    const StreamWalk w = stream_walk<U>(nchunks, cpr, inv && rev);   // rev: each XCD's eighth of the tensor, descending
     float a[8], b[8], c[8];
-    if (inv) { load8(cA, ch0, a); load8(cB, ch0, b); load8(cC, ch0, c); }
-    long i = i0;
-    for (long it = 0; it < count; ++it, i += step) {
-        const uint4 gv = ld16<NT>(dy + i * 8);   // NT: last use of both operands
-        const uint4 xv = ld16<NT>(x + i * 8);
-        unsigned m = 0xffu;
-        if (RELU) m = mask[i];
-        if (!inv) {
-            const int ch = (int)(i % cpr);
-            load8(cA, ch, a); load8(cB, ch, b); load8(cC, ch, c);
-        }
-        float g[8], xf[8];
-        unpack8(gv, g); unpack8(xv, xf);
-        if (RELU) {
+    if (inv) { load8(cA, w.ch0, a); load8(cB, w.ch0, b); load8(cC, w.ch0, c); }
+    for (long j0 = w.off0; j0 < w.R; j0 += w.sweep) {
+        uint4 gv[U], xv[U];
+        unsigned mk[U];
+        long idx[U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] = ((m >> j) & 1u) ? g[j] : 0.f;
+        for (int u = 0; u < U; ++u) {
+            const long j = j0 + u * 256;
+            idx[u] = j < w.R ? w.base + w.dir * j : -1;
+            mk[u] = 0xffu;
+            if (idx[u] >= 0) {
+                gv[u] = ld16<NT>(dy + idx[u] * 8);   // NT: last use of both operands
+                xv[u] = ld16<NT>(x + idx[u] * 8);
+                if (RELU) mk[u] = mask[idx[u]];
+            }
         }
-        float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(a[j], g[j], __builtin_fmaf(b[j], xf[j], c[j]));   // same association as tail_bwd.hip
-        *(uint4*)(dx + i * 8) = pack8(o);
+        for (int u = 0; u < U; ++u) {
+            const long i = idx[u];
+            if (i < 0) continue;
+            if (!inv) {
+                const int ch = (int)(i % cpr);
+                load8(cA, ch, a); load8(cB, ch, b); load8(cC, ch, c);
+            }
+            float g[8], xf[8];
+            unpack8(gv[u], g); unpack8(xv[u], xf);
+            if (RELU) {
+                const unsigned m = mk[u];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g[k] = ((m >> k) & 1u) ? g[k] : 0.f;
+            }
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = __builtin_fmaf(a[k], g[k], __builtin_fmaf(b[k], xf[k], c[k]));   // same association as tail_bwd.hip
+            st16(dx + i * 8, pack8(o), nts);
+        }
     }
 }
 
@@ -547,6 +579,29 @@ inline int stream_grid(long nchunks) {
     return (int)b;
 }
 
+// DPA_BN_UNROLL (1 or 4, default 4): 16-byte chunks per thread per iteration of bn_apply / bn_bwd_apply, all loads first.
+// DPA_BN_GRID: workgroup cap of those launches (default 16384 unrolled, 4096 otherwise).  scripts/stream_probe.hip, 822 MB
+// operands, 2 reads + 1 write: 1 chunk / 4096 workgroups 4.2-4.4 TB/s, 4 chunks / 16384 workgroups 5.6-5.7 TB/s.
+inline int bn_unroll() {
+    static const int v = [] { const char* e = getenv("DPA_BN_UNROLL"); return e ? (atoi(e) >= 4 ? 4 : 1) : 4; }();
+    return v;
+}
+inline int stream_grid_u(long nchunks, int unroll) {
+    static const long cap_env = [] { const char* e = getenv("DPA_BN_GRID"); return e ? atol(e) : 0L; }();
+    const long cap = cap_env > 0 ? cap_env / 8 * 8 : (unroll > 1 ? 16384 : 4096);
+    long b = (nchunks + 256L * unroll - 1) / (256L * unroll);
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+// DPA_BN_NTS_MB: outputs of at least this many MB leave bn_apply / bn_bwd_apply through non-temporal stores (0 = never).
+// A tensor several times the 256 MB Infinity Cache only passes through it: the probe gains 8 % at 822 MB per operand and
+// loses 3-5 % at 205 MB, where the consumer would have found the output in the cache.
+inline long bn_nts_bytes() {
+    static const long v = [] { const char* e = getenv("DPA_BN_NTS_MB"); return (e ? atol(e) : 0L) * 1000000L; }();
+    return v;
+}
+
 }  // namespace
 
 void fold_rows(const float* in, int rows, int cols, int chunk, float* out, hipStream_t st) {
@@ -571,16 +626,19 @@ void bn_apply(const void* x, const void* residual, void* y, const float* scale, 
               unsigned char* mask, long P, int C, int relu, const float* rscale, const float* rshift, hipStream_t st) {
     const long nchunks = P * C / 8;
     const int cpr = C / 8;
-    dim3 g(stream_grid(nchunks)), b(256);
     auto X = (const unsigned short*)x; auto R = (const unsigned short*)residual; auto Y = (unsigned short*)y;
     const bool inv = 256 % cpr == 0 && bn_inv_enabled();   // a thread never leaves its channel group (see the kernel)
     const bool nt = bn_nt_enabled() & 1, ntr = (bn_nt_enabled() & 2) != 0;
+    const bool unr = inv && nt && ntr && bn_unroll() == 4;
+    dim3 g(unr ? stream_grid_u(nchunks, 4) : stream_grid(nchunks)), b(256);
     const int rev = ((bn_rev_enabled() & 1) && inv && g.x % 8 == 0 && nchunks % 2048 == 0) ? 1 : 0;
+    const int nts = bn_nts_bytes() > 0 && nchunks * 16 >= bn_nts_bytes() ? 1 : 0;
 #define DPA_BN_APPLY(RELU_, RES_)                                                                                     \
-    if (inv && nt && ntr) hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, true, true, true>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift, rev); \
-    else if (inv && nt) hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, true, true>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift, rev); \
-    else if (inv)  hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, true, false>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift, rev); \
-    else           hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, false, false>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift, rev)
+    if (unr) hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, true, true, true, 4>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift, rev, nts); \
+    else if (inv && nt && ntr) hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, true, true, true>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift, rev, nts); \
+    else if (inv && nt) hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, true, true>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift, rev, nts); \
+    else if (inv)  hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, true, false>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift, rev, nts); \
+    else           hipLaunchKernelGGL((bn_apply_kernel<RELU_, RES_, false, false>), g, b, 0, st, X, R, Y, scale, shift, mask, nchunks, cpr, rscale, rshift, rev, nts)
     if (relu) { if (R) { DPA_BN_APPLY(true, true); } else { DPA_BN_APPLY(true, false); } }
     else      { if (R) { DPA_BN_APPLY(false, true); } else { DPA_BN_APPLY(false, false); } }
 #undef DPA_BN_APPLY
@@ -606,20 +664,24 @@ void bn_bwd_apply(const void* dy, const unsigned char* mask, const void* x, cons
                   const float* coefC, void* dx, long P, int C, int relu, hipStream_t st) {
     const long nchunks = P * C / 8;
     const int cpr = C / 8;
-    dim3 g(stream_grid(nchunks)), b(256);
     auto DY = (const unsigned short*)dy; auto X = (const unsigned short*)x;
     auto DX = (unsigned short*)dx;
     const bool inv = 256 % cpr == 0 && bn_inv_enabled();
     const bool nt = bn_nt_enabled() & 1;
+    const bool unr = inv && nt && bn_unroll() == 4;
+    dim3 g(unr ? stream_grid_u(nchunks, 4) : stream_grid(nchunks)), b(256);
     const int rev = (bn_rev_enabled() & 2) && inv && g.x % 8 == 0 && nchunks % 2048 == 0 ? 1 : 0;
+    const int nts = bn_nts_bytes() > 0 && nchunks * 16 >= bn_nts_bytes() ? 1 : 0;
     if (relu) {
-        if (inv && nt) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true, true>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev);
-        else if (inv)  hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev);
-        else           hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev);
+        if (unr)       hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true, true, 4>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev, nts);
+        else if (inv && nt) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true, true>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev, nts);
+        else if (inv)  hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev, nts);
+        else           hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev, nts);
     } else {
-        if (inv && nt) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true, true>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev);
-        else if (inv)  hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev);
-        else           hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev);
+        if (unr)       hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true, true, 4>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev, nts);
+        else if (inv && nt) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true, true>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev, nts);
+        else if (inv)  hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev, nts);
+        else           hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false, false>), g, b, 0, st, DY, mask, X, coefA, coefB, coefC, DX, nchunks, cpr, rev, nts);
     }
 }
 

@@ -165,7 +165,16 @@ class GPT2(nn.Module):
         return ops.linear(x, self.emb.wte, self.emb.wte_lp, None, weight_lp_t=self.emb.wte_lp_t)
 
     def loss(self, tokens: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
-        logits = self.forward(tokens)
+        from ..ops import lmhead
+        rows = tokens.numel()
+        if lmhead.chunk_rows_for(rows, self.cfg.vocab_padded):
+            # [rows, 50,304] logits would not fit one GEMM operand (32 x 1024 tokens: 1.65 G elements): head + loss row-chunked
+            x = self.hidden(tokens)
+            if lmhead.usable(x, self.emb.wte_lp, self.cfg.vocab_size):
+                return lmhead.lm_head_loss(x, self.emb.wte, self.emb.wte_lp, self.emb.wte_lp_t, targets, self.cfg.vocab_size)
+            logits = ops.linear(x, self.emb.wte, self.emb.wte_lp, None, weight_lp_t=self.emb.wte_lp_t)
+        else:
+            logits = self.forward(tokens)
         return ops.softmax_cross_entropy(logits.reshape(-1, logits.shape[-1]), targets.reshape(-1),
                                          self.cfg.vocab_size, inplace_backward=True)
 

@@ -388,16 +388,15 @@ def test_native_rccl_communicator_single_rank():
     torch.testing.assert_close(dst, want, rtol=8e-3, atol=1e-3)
 
 
-def test_native_grouped_send_recv_runs_on_one_gpu_as_a_self_exchange():
-    """ncclSend / ncclRecv through ``RcclComm.batch_p2p`` on the one GPU a box has: a rank may exchange with ITSELF
-    when the send and the matching receive sit in one group (RCCL then copies locally) - the same C++ path, group
-    calls, comm-stream ordering and ticket hand-off that carry the pipeline's stage boundaries between GPUs.  Under a
-    host watchdog: a transfer that does not complete aborts the communicator instead of hanging the test."""
+def _self_exchange_worker(local_rank, global_rank, world_size, out_dir):
+    import os
     import time
+    import torch
     from distributedpytorch_amd.ops import _ext
     C = _ext.load()
-    nc = C.RcclComm(C.RcclComm.unique_id(), 0, 1, torch.cuda.current_device())
-    a = (torch.arange(1 << 20, device=DEV, dtype=torch.float32) * 0.5).to(torch.bfloat16)
+    torch.cuda.set_device(0)
+    nc = C.RcclComm(C.RcclComm.unique_id(), 0, 1, 0)
+    a = (torch.arange(1 << 20, device="cuda", dtype=torch.float32) * 0.5).to(torch.bfloat16)
     src = a * 2                                          # producer on the compute stream
     dst = torch.zeros_like(src)
     ticket = nc.batch_p2p([(True, src, 0), (False, dst, 0)])
@@ -405,13 +404,29 @@ def test_native_grouped_send_recv_runs_on_one_gpu_as_a_self_exchange():
     while not nc.query(ticket):
         if time.monotonic() - t0 > 30.0:
             nc.abort()
-            pytest.fail("grouped self send/recv did not complete in 30 s")
+            raise RuntimeError("grouped self send/recv did not complete in 30 s")
         time.sleep(0.001)
     nc.wait(ticket)
-    assert torch.equal(dst + 0, a * 2)                   # consumer on the compute stream, ordered behind the ticket
-    with pytest.raises(RuntimeError, match="matching receive"):
+    ok = bool(torch.equal(dst + 0, a * 2))               # consumer on the compute stream, ordered behind the ticket
+    refused = False
+    try:
         nc.batch_p2p([(True, src, 0)])                   # a lone transfer to oneself could never complete: refused
+    except RuntimeError as e:
+        refused = "matching receive" in str(e)
     nc.synchronize()
+    torch.save({"ok": ok, "refused": refused}, os.path.join(out_dir, "self.pt"))
+
+
+def test_native_grouped_send_recv_runs_on_one_gpu_as_a_self_exchange(tmp_path):
+    """ncclSend / ncclRecv through ``RcclComm.batch_p2p`` on the one GPU a box has: a rank may exchange with ITSELF
+    when the send and the matching receive sit in one group (RCCL then copies locally) - the same C++ path, group
+    calls, comm-stream ordering and ticket hand-off that carry the pipeline's stage boundaries between GPUs.  Under a
+    host watchdog, and in a process of its own: RCCL's self-transfer path is not one the training runs ever take, and a
+    communicator created in the same process right after it stalled under bucket-sized traffic on one box."""
+    from distributedpytorch_amd import launch
+    launch.spawn(_self_exchange_worker, [1], 0, args=(str(tmp_path),))
+    r = torch.load(tmp_path / "self.pt", weights_only=True)
+    assert r["ok"] and r["refused"]
 
 
 def test_native_rccl_layer_under_bucket_sized_traffic():

@@ -173,3 +173,25 @@ def test_wide_gemm_split_k_slabs_fold_to_the_same_result(M, K, N, splitk):
 def test_wide_gemm_is_what_large_launches_use_by_default_and_small_ones_do_not():
     C = _C()
     assert C.wide_gemm_min_tiles() > 0, "the wide kernel must be on by default (DPA_WIDE_MIN_TILES=0 disables it)"
+
+
+def test_split_k_workspace_comes_from_torchs_caching_allocator():
+    """The split-K slabs (fp32, split x M x N) are taken from torch's caching allocator for the launch's stream and handed
+    back behind the fold kernel: visible to torch.cuda.memory_*, not a private hipMalloc that grows and is never freed."""
+    C = _C()
+    M, K, N, S = 4096, 1024, 512, 4
+    x = _rand((M, 1, 1, K), 1.0, 21)
+    w = _rand((N, 1, 1, K), 0.1, 22)
+    with _Wide(True, splitk=S):
+        C.conv_fprop(x, w, None, 1, 0, 0, False, None)                     # warm: code object, allocator pools
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        y = C.conv_fprop(x, w, None, 1, 0, 0, False, None)[0]
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() - base
+    slabs = S * M * N * 4
+    assert peak >= slabs, f"peak {peak} bytes does not include the {slabs}-byte split-K workspace"
+    assert torch.cuda.memory_allocated() - base <= y.numel() * 2 + (1 << 20)    # ... and it was handed back
+    ref = x.float().view(M, K) @ w.float().view(N, K).t()
+    assert float((y.view(M, N).float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max()) + 1e-3

@@ -312,3 +312,79 @@ def test_tiny_resnet_gradient_error_is_what_stock_bf16_gives():
     # observed on MI355X: ours 0.170, stock bf16 autocast 0.175 - the distance from fp32 is bf16's, not these kernels'
     assert e_ours < max(2.0 * e_stock, 0.03) + 0.02, (e_ours, e_stock)
     assert e_ours < 0.2
+
+
+def _lm_head_reference(x, w, t, n_classes, rows_chunk=2048):
+    """fp32 oracle of mean CE((x @ w^T)[:, :n_classes], t) with its gradients w.r.t. x and w, row-chunked so that the
+    [rows, vocab] logits never exist at once either."""
+    rows = x.shape[0]
+    xf, wf = x.float(), w.float()[:n_classes]
+    loss = torch.zeros((), device=x.device, dtype=torch.float64)
+    dx = torch.empty_like(xf)
+    dw = torch.zeros_like(wf)
+    for r0 in range(0, rows, rows_chunk):
+        lg = xf[r0:r0 + rows_chunk] @ wf.t()
+        lse = torch.logsumexp(lg, dim=1)
+        tt = t[r0:r0 + rows_chunk]
+        loss += (lse - lg.gather(1, tt[:, None])[:, 0]).double().sum()
+        p = torch.softmax(lg, dim=1)
+        p[torch.arange(p.shape[0], device=x.device), tt] -= 1.0
+        p /= rows
+        dx[r0:r0 + rows_chunk] = p @ wf
+        dw += p.t() @ xf[r0:r0 + rows_chunk]
+    return float(loss / rows), dx, dw
+
+
+@pytest.mark.parametrize("rows,chunk", [(4096, 1024), (3000, 1024)])
+def test_chunked_lm_head_loss_matches_the_unchunked_path(rows, chunk):
+    """ops/lmhead.py against ops.linear + ops.softmax_cross_entropy at GPT-2's head shape (768 -> 50,304 padded columns,
+    50,257 classes), ragged last chunk included: same loss, same input gradient, same weight gradient."""
+    from distributedpytorch_amd import ops
+    from distributedpytorch_amd.ops import lmhead
+    torch.manual_seed(3)
+    V, Vp, Cin = 50257, 50304, 768
+    w = torch.zeros(Vp, Cin, device=DEV)
+    w[:V] = torch.randn(V, Cin, device=DEV) * 0.02
+    w_lp = w.to(torch.bfloat16)
+    x0 = (torch.randn(rows, Cin, device=DEV)).to(torch.bfloat16)
+    t = torch.randint(0, V, (rows,), device=DEV)
+    wa = w.clone().requires_grad_(True)
+    xa = x0.clone().requires_grad_(True)
+    la = lmhead.lm_head_loss(xa, wa, w_lp, None, t, V, chunk_rows=chunk)
+    la.backward()
+    wb = w.clone().requires_grad_(True)
+    xb = x0.clone().requires_grad_(True)
+    lb = ops.softmax_cross_entropy(ops.linear(xb, wb, w_lp), t, V, inplace_backward=True)
+    lb.backward()
+    assert abs(float(la) - float(lb)) < 2e-3 * abs(float(lb))
+    assert _rel(xa.grad.float(), xb.grad.float()) < 0.02
+    assert _rel(wa.grad, wb.grad) < 0.02
+    ref_loss, ref_dx, ref_dw = _lm_head_reference(x0, w_lp, t, V)
+    assert abs(float(la) - ref_loss) < 5e-3 * abs(ref_loss)
+    assert _rel(xa.grad.float(), ref_dx) < 0.03 and _rel(wa.grad[:V], ref_dw) < 0.03
+
+
+def test_lm_head_loss_at_32x1024_tokens_beyond_the_one_operand_limit():
+    """32 x 1024 x 50,304 logits are 1.65 G elements - past the 2^30-element range of one GEMM operand, which capped
+    GPT-2 at batch 20.  Row-chunked (8 x 4,096 rows here) the head + loss run, and agree with a chunked fp32 oracle:
+    the loss over all rows, the input gradient on sampled rows, the weight gradient in aggregate."""
+    from distributedpytorch_amd.ops import lmhead
+    torch.manual_seed(5)
+    rows, V, Vp, Cin = 32 * 1024, 50257, 50304, 768
+    assert lmhead.chunk_rows_for(rows, Vp) > 0 and lmhead.chunk_rows_for(16 * 1024, Vp) == lmhead._FORCE_ROWS
+    w = torch.zeros(Vp, Cin, device=DEV)
+    w[:V] = torch.randn(V, Cin, device=DEV) * 0.02
+    w_lp = w.to(torch.bfloat16)
+    x0 = torch.randn(rows, Cin, device=DEV).to(torch.bfloat16)
+    t = torch.randint(0, V, (rows,), device=DEV)
+    wa = w.clone().requires_grad_(True)
+    xa = x0.clone().requires_grad_(True)
+    loss = lmhead.lm_head_loss(xa, wa, w_lp, None, t, V, chunk_rows=4096)
+    loss.backward()
+    torch.cuda.synchronize()
+    ref_loss, ref_dx, ref_dw = _lm_head_reference(x0, w_lp, t, V)
+    assert abs(float(loss) - ref_loss) < 5e-3 * abs(ref_loss), (float(loss), ref_loss)
+    sample = torch.randint(0, rows, (256,), device=DEV)
+    assert _rel(xa.grad.float()[sample], ref_dx[sample]) < 0.03
+    assert _rel(wa.grad[:V], ref_dw) < 0.03
+    assert float(wa.grad[V:].abs().max()) == 0.0            # padding rows of the vocabulary take no gradient
