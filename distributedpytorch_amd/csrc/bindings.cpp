@@ -1117,6 +1117,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         Guard g(dst);
         dpa::reduce_shards_bf16(dst.data_ptr<float>(), src.data_ptr(), (int)nsrc, stride, dst.numel(), out.data_ptr(), cur_stream());
     });
+    m.def("set_conv3x3_halo", [](bool on) { dpa::set_conv3x3_halo(on ? 1 : 0); });
+    m.def("conv3x3_halo_enabled", []() { return dpa::conv3x3_halo_enabled() != 0; });
     m.def("set_wide_gemm_min_tiles", [](int64_t n) { dpa::set_wide_gemm_min_tiles((int)n); });
     m.def("set_wide_gemm_splitk", [](int64_t n) { dpa::set_wide_gemm_splitk((int)n); });
     m.def("wide_gemm_min_tiles", []() { return (int64_t)dpa::wide_gemm_min_tiles(); });

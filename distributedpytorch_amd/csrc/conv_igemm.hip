@@ -716,6 +716,7 @@ static int staging(const ConvArgs& a, bool one) {
 
 void conv_igemm(const ConvArgs& a, hipStream_t st) {
     if (wide_gemm_eligible(a)) { gemm_wide(a, st); return; }     // large plain GEMMs: the 256 x 256 main loop
+    if (conv3x3_halo_ok(a)) { conv3x3_halo(a, st); return; }     // stage-1 3 x 3 layers: halo-tiled, filter in registers
     // 1x1 / no padding: plain GEMM gather (strided fprop included; strided dgrad goes by parity class)
     const bool one = a.R == 1 && a.S == 1 && a.pad == 0 && (a.mode == 0 || a.stride == 1);
     const int stg = staging(a, one);

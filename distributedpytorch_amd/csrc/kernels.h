@@ -67,6 +67,13 @@ typedef void* (*WorkspaceAlloc)(size_t bytes, hipStream_t stream);
 typedef void (*WorkspaceFree)(void* ptr);
 void set_workspace_allocator(WorkspaceAlloc alloc, WorkspaceFree free_);
 
+// halo-tiled 3 x 3 / stride 1 / pad 1 forward + input gradient for 64 -> 64 channels on 56-wide maps (conv3x3_halo.hip);
+// conv_igemm routes eligible launches to it
+bool conv3x3_halo_ok(const ConvArgs& a);
+void conv3x3_halo(const ConvArgs& a, hipStream_t st);
+void set_conv3x3_halo(int on);      // tests / A-B runs: route eligible launches to the halo kernel (1) or to conv_igemm (0)
+int conv3x3_halo_enabled();
+
 // wgrad: dw[k,r,s,c] += sum_{n,ho,wo} dy[n,ho,wo,k] * x[n, ho*stride-pad+r, wo*stride-pad+s, c]
 // dw is fp32 and is accumulated into with float atomics (split over the pixel axis).
 struct WgradArgs {

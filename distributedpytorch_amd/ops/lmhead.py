@@ -55,7 +55,7 @@ class _LMHeadLossFn(torch.autograd.Function):
         for r0 in range(0, rows, chunk):
             r1 = min(rows, r0 + chunk)
             xc = x2d[r0:r1].view(r1 - r0, 1, 1, cin)
-            logits, _ = C.conv_fprop(xc, w4, None, 1, 0, 0, False, None)
+            logits = C.conv_fprop(xc, w4, None, 1, 0, 0, False, None)[0]
             g2 = logits.view(r1 - r0, cout)
             part = C.softmax_ce_fused(g2, targets[r0:r1], n_classes, scale, ignore_index)      # g2 now holds d loss / d logits
             loss = part if loss is None else loss + part
