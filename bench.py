@@ -59,7 +59,8 @@ def parse():
     p.add_argument("--breakdown", action="store_true",
                    help="HIP-event phase timers: forward / backward / exposed communication / optimizer per step, added to the JSON")
     p.add_argument("--comm", default=None, choices=["native", "c10d"], help="collective layer under RCCL (default: DPA_COMM or native)")
-    p.add_argument("--allreduce", default=None, choices=["ring", "direct"], help="native layer: RCCL's ring or the one-shot direct algorithm")
+    p.add_argument("--allreduce", default=None, choices=["ring", "direct", "ipc"],
+                   help="RCCL's ring, the one-shot direct algorithm over grouped send/recv, or ONE kernel over hipIpc-mapped peer memory (csrc/peer_allreduce.hip)")
     p.add_argument("--grad-wire", default=None, choices=["fp32", "bf16"], help="direct all-reduce: gradient format on the links")
     return p.parse_args()
 
@@ -272,8 +273,11 @@ def main():
         layer = "native (csrc/rccl_comm.cpp)" if communicator.native is not None else \
             ("c10d" if torch.distributed.is_initialized() else "none (single process, no collectives)")
         no_comm = communicator.native is None and not torch.distributed.is_initialized()
+        communicator.check_peer()     # a bounded poll of the peer-mapped kernel that ran out would have left wrong sums behind
         if no_comm:
             algo = None               # nothing is reduced: no algorithm to name
+        elif communicator.peer is not None:
+            algo = "ipc/" + communicator.grad_wire + " (one kernel over peer-mapped memory)"
         elif communicator.native is not None and communicator._direct:
             algo = "direct/" + communicator.grad_wire
         else:

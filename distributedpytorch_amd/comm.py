@@ -41,6 +41,15 @@ _SELFTEST_TIMEOUT_S = float(os.environ.get("DPA_COMM_SELFTEST_TIMEOUT", "60"))
 _CONTROL_PLANE = os.environ.get("DPA_CONTROL_PLANE", "gloo").lower()
 # blocking native send() / recv(): host watchdog (seconds) instead of a silent hang on an unmatched transfer
 _P2P_TIMEOUT_S = float(os.environ.get("DPA_P2P_TIMEOUT", "120"))
+# All-reduce algorithm for fp32 sums on GPU tensors: "ring" = RCCL's ncclAllReduce, "direct" = one-shot reduce-scatter +
+# all-gather as grouped RCCL send/recv (rccl_comm.cpp), "ipc" = ONE kernel over hipIpc-mapped peer memory
+# (csrc/peer_allreduce.hip; needs every rank of the group on one xGMI node, at most 8; self-tested at start-up, and every
+# rank falls back to the RCCL path when any rank fails it).  DPA_PEER_CHUNK_MB: staging bytes per launch (default 64),
+# DPA_PEER_BLOCKS: workgroups per launch (default 32, the CUs the reduction may take from the backward pass).
+_ALLREDUCE = os.environ.get("DPA_ALLREDUCE", "ring").lower()
+_PEER_CHUNK_MB = int(os.environ.get("DPA_PEER_CHUNK_MB", "64"))
+_PEER_BLOCKS = int(os.environ.get("DPA_PEER_BLOCKS", "32"))
+_PEER_TIMEOUT_S = float(os.environ.get("DPA_PEER_TIMEOUT", "30"))
 
 
 def set_sync_debug(flag: bool) -> None:
@@ -119,6 +128,8 @@ def init_process_group(backend: str = "auto", init_method: Optional[str] = None,
         # the native layer is not there (never created, or it failed its self-test on some rank): device traffic
         # goes through c10d's ProcessGroupNCCL after all - created now, collectively, and only now
         comm._adopt_c10d_nccl()
+    if _ALLREDUCE == "ipc" and on_gpu and comm.world_size > 1:
+        comm.attach_peer()
     return comm
 
 
@@ -141,6 +152,8 @@ def init_native_group(init_method: str, rank: int, world_size: int, device: torc
     comm = Communicator(group=None, device=device, ranks=None, static=(rank, world_size), store=store)
     comm.native = C.RcclComm(uid, rank, world_size, index)
     comm._selftest_native(strict=True)
+    if _ALLREDUCE == "ipc" and world_size > 1:
+        comm.attach_peer()
     return comm
 
 
@@ -169,6 +182,20 @@ class _NativeWork:
 
     def is_completed(self):
         return bool(self._native.query(self._ticket))
+
+
+class _PeerWork:
+    """Handle of an all-reduce on the peer-mapped layer's stream (csrc/peer_comm.cpp)."""
+
+    def __init__(self, peer, ticket: int):
+        self._peer, self._ticket = peer, ticket
+
+    def wait(self):
+        self._peer.wait(self._ticket)        # the current compute stream waits on the event; no host block
+        return True
+
+    def is_completed(self):
+        return bool(self._peer.query(self._ticket))
 
 
 class _DoneWork:
@@ -214,9 +241,10 @@ class Communicator:
         self.store = store                    # store.TCPKVStore of such a communicator (objects, bootstrap)
         self.initialized = dist.is_initialized() and static is None
         self.native = None                    # csrc/rccl_comm.cpp communicator over the same ranks
+        self.peer = None                      # csrc/peer_comm.cpp: all-reduce over hipIpc-mapped peer memory (DPA_ALLREDUCE=ipc)
         # all-reduce algorithm of the native layer: "ring" = RCCL's own ncclAllReduce, "direct" = one-shot
         # reduce-scatter + all-gather over the 7 xGMI links (rccl_comm.cpp); wire format of the direct form
-        self._direct = os.environ.get("DPA_ALLREDUCE", "ring").lower() == "direct"
+        self._direct = _ALLREDUCE == "direct"
         self.grad_wire = os.environ.get("DPA_GRAD_WIRE", "fp32").lower()
         self._scratch = {}
         self._obj_seq = 0
@@ -376,6 +404,125 @@ class Communicator:
                 pass
             self.native = None
 
+    # ---- peer-mapped all-reduce: one kernel over hipIpc-mapped staging buffers ----
+    def _exchange(self, obj):
+        """All-gather of a small picklable object over the control plane (c10d group, or the TCP store of a c10d-free
+        communicator).  Collective over this communicator."""
+        if self._static is not None:
+            key = self._obj_key("xchg")
+            self.store.set_object(f"{key}/{self.rank}", obj)
+            return [self.store.get_object(f"{key}/{r}") for r in range(self.world_size)]
+        out = [None] * self.world_size
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def _agree(self, ok: bool) -> bool:
+        """True when EVERY rank of this communicator passed ``ok`` (decided on the control plane: the ranks cannot
+        end up on different paths)."""
+        if self.world_size <= 1:
+            return ok
+        return all(self._exchange(bool(ok)))
+
+    def attach_peer(self) -> None:
+        """Collective over this communicator: allocate staging + signal memory, exchange the hipIpc handles over the
+        control plane, map every peer, self-test.  Leaves ``self.peer`` None (all ranks alike) when anything fails -
+        all-reduces then stay on the RCCL / c10d path."""
+        import sys
+        from .ops import _ext
+        peer, ok, why = None, True, ""
+        try:
+            if self.device is None or self.device.type != "cuda":
+                raise RuntimeError("needs a GPU device")
+            C = _ext.load()
+            if self.world_size > C.PEER_MAX_RANKS:
+                raise RuntimeError(f"{self.world_size} ranks > {C.PEER_MAX_RANKS} (one xGMI node)")
+            index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            peer = C.PeerAllReduce(self.rank, self.world_size, index, _PEER_CHUNK_MB << 20, _PEER_BLOCKS, _PEER_TIMEOUT_S)
+            mine = peer.handles()
+        except Exception as e:  # noqa: BLE001
+            ok, why, mine = False, f"{type(e).__name__}: {e}", None
+        everyone = self._exchange(mine)
+        if ok and any(h is None for h in everyone):
+            ok, why = False, "another rank could not allocate / export its buffers"
+        if ok:
+            try:
+                peer.open([(bytes(a), bytes(b)) for a, b in everyone])
+            except Exception as e:  # noqa: BLE001 - e.g. GPUs without peer access, a handle from another node
+                ok, why = False, f"{type(e).__name__}: {e}"
+        if not self._agree(ok):
+            if not ok:
+                print(f"[comm] rank {self.global_rank}: peer-mapped all-reduce unavailable ({why}); staying on RCCL",
+                      file=sys.stderr, flush=True)
+            return
+        self.peer = peer
+        ok, why = self._selftest_peer()
+        if not self._agree(ok):
+            print(f"[comm] rank {self.global_rank}: peer-mapped all-reduce failed its self-test"
+                  f"{' here (' + why + ')' if not ok else ' on another rank'}; staying on RCCL", file=sys.stderr, flush=True)
+            self.peer = None
+
+    def _selftest_peer(self):
+        """A ragged small tensor, one larger than a staging chunk, and the bf16 wire format, each under a host watchdog
+        and checked element by element; then the kernel's own time-out word."""
+        import time
+        W, r, dev = self.world_size, self.rank, self.device
+        cases, ok, why = [], True, ""
+        try:
+            chunk = int(self.peer.chunk_elems)
+            for n, bf16 in ((1003, False), (chunk + 4099, False), (70001, True)):
+                base = (torch.arange(n, dtype=torch.float32, device=dev) % 61.0) * 0.25       # exact in bf16
+                cases.append((n, bf16, base, base + float(r + 1)))
+            torch.cuda.synchronize(dev)
+        except Exception as e:  # noqa: BLE001
+            ok, why = False, f"{type(e).__name__}: {e}"
+        # The kernel's polls are bounded, so the ranks must ENTER it within that bound of one another.  In steady state
+        # the previous collective keeps them within a step's imbalance; at first contact they can be tens of seconds
+        # apart (a cold process loads its code objects on its first device operation): finish every device-side
+        # preparation, meet on the control plane, then launch.
+        if not self._agree(ok):
+            return False, why or "another rank could not prepare the self-test"
+        try:
+            for n, bf16, base, t in cases:
+                ticket = self.peer.all_reduce(t, 1.0, bf16)
+                t0 = time.monotonic()
+                while not self.peer.query(ticket):
+                    if time.monotonic() - t0 > _SELFTEST_TIMEOUT_S:
+                        raise TimeoutError(f"peer all-reduce of {n} floats did not complete in {_SELFTEST_TIMEOUT_S:.0f} s")
+                    time.sleep(0.0005)
+                self.peer.wait(ticket)
+                took = time.monotonic() - t0
+                if self.peer.error_seq() != 0:
+                    d = int(self.peer.error_detail())
+                    raise RuntimeError(f"launch {self.peer.error_seq()}: barrier {'AB'[(d >> 16) & 1]} of block {(d >> 8) & 255} "
+                                       f"never saw rank {d & 255} ({took:.1f} s; the ranks' kernels must run at the same time)")
+                want = base * W + W * (W + 1) / 2.0
+                bad = int((t != want).sum().item())
+                if bad:
+                    raise RuntimeError(f"peer all-reduce of {n} floats (bf16 wire {bf16}): {bad} wrong elements after {took:.2f} s")
+            return True, ""
+        except Exception as e:  # noqa: BLE001
+            return False, f"{type(e).__name__}: {e}"
+
+    def check_peer(self) -> None:
+        """Raise if a bounded poll of the peer-mapped all-reduce ever ran out on this rank (a peer did not arrive at a
+        barrier within DPA_PEER_TIMEOUT seconds: the kernel then finished with wrong sums instead of hanging the queue).
+        One small device-to-host copy: for synchronisation points (end of an epoch, of a benchmark, before a checkpoint)."""
+        if self.peer is None:
+            return
+        seq = int(self.peer.error_seq())
+        if seq != 0:
+            d = int(self.peer.error_detail())
+            raise RuntimeError(f"rank {self.global_rank}: peer-mapped all-reduce launch {seq}: barrier {'AB'[(d >> 16) & 1]} of "
+                               f"workgroup {(d >> 8) & 255} never saw rank {d & 255} within {_PEER_TIMEOUT_S:.0f} s; the sums "
+                               f"since then are wrong")
+
+    def _peer_all_reduce(self, tensor: torch.Tensor, op):
+        if op != dist.ReduceOp.SUM or tensor.dtype != torch.float32 or not (tensor.is_cuda and tensor.is_contiguous()):
+            return None
+        if tensor.data_ptr() % 16 != 0:
+            return None
+        return _PeerWork(self.peer, self.peer.all_reduce(tensor, 1.0, self.grad_wire == "bf16"))
+
     def _on_native(self, *tensors: torch.Tensor) -> bool:
         return self.native is not None and all(t.is_cuda and t.is_contiguous() for t in tensors)
 
@@ -465,6 +612,15 @@ class Communicator:
     def all_reduce(self, tensor: torch.Tensor, op=dist.ReduceOp.SUM, async_op: bool = False):
         if self._single():
             return _DoneWork() if async_op else None
+        if self.peer is not None:
+            work = self._peer_all_reduce(tensor, op)
+            if work is not None:
+                if _SYNC_DEBUG:
+                    self.peer.synchronize()
+                if async_op:
+                    return work
+                work.wait()
+                return None
         if self.native is not None:
             work = self._native_all_reduce(tensor, op)
             if work is not None:
@@ -730,6 +886,8 @@ class Communicator:
             sub = Communicator(group=None, device=self.device, ranks=ranks,
                                static=(ranks.index(self.global_rank) if member else 0, len(ranks)), store=self.store)
             sub.attach_native(parent=self, member=member)
+            if member and self.peer is not None and len(ranks) > 1:
+                sub.attach_peer()
             return sub if member else None
         group = dist.new_group(ranks=ranks, backend=self._c10d_sub_backend)
         sub = Communicator(group=group, device=self.device, ranks=ranks) if member else None
@@ -740,10 +898,18 @@ class Communicator:
                 sub.attach_native(parent=self, member=True)
             else:                                            # ncclCommSplit is collective over the parent
                 Communicator(group=None, device=self.device, ranks=ranks, static=(0, 1)).attach_native(parent=self, member=False)
+        if sub is not None and self.peer is not None and len(ranks) > 1:
+            sub.attach_peer()                                # collective over the members only (their own control-plane group)
         return sub
 
     def close(self) -> None:
         """Release the native communicator and the rendezvous store of a c10d-free communicator."""
+        if self.peer is not None:
+            self.peer.synchronize()
+            try:
+                self.check_peer()
+            finally:
+                self.peer = None
         if self.native is not None:
             self.native.synchronize()
             self.native = None

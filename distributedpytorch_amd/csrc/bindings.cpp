@@ -1020,6 +1020,7 @@ Tensor mul_f32(const Tensor& a, const Tensor& b) {
 
 void bind_transformer(pybind11::module_& m);  // bindings_tfm.cpp
 void bind_rccl(pybind11::module_& m);         // rccl_comm.cpp
+void bind_peer(pybind11::module_& m);         // peer_comm.cpp
 
 // Launcher temporaries (gemm_wide's split-K slabs) come from torch's caching allocator: visible to torch.cuda.memory_*,
 // shared with the step's other temporaries, re-issued only to later work of the stream they were taken for.
@@ -1124,4 +1125,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("wide_gemm_min_tiles", []() { return (int64_t)dpa::wide_gemm_min_tiles(); });
     bind_transformer(m);
     bind_rccl(m);
+    bind_peer(m);
 }

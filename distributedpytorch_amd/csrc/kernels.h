@@ -268,4 +268,25 @@ void axpy_dev(float* dst, const float* src, long n, const float* g, hipStream_t 
 // dst[i] += sum_{k<nsrc} bf16 src[k*stride + i] in fp32; out[i] = bf16(dst[i])  (bf16 wire format of the direct all-reduce)
 void reduce_shards_bf16(float* dst, const void* src, int nsrc, long stride, long n, void* out, hipStream_t st);
 
+// ---------------------------------------------------------------- peer-mapped all-reduce (peer_allreduce.hip, peer_comm.cpp)
+constexpr int PEER_MAX_RANKS = 8;          // one xGMI-connected node
+constexpr int PEER_MAX_BLOCKS = 64;        // workgroups of one launch = rows of the signal arrays
+constexpr int PEER_ERR_WORD = 2 * PEER_MAX_BLOCKS * 16;       // signal block: A[blocks][16], B[blocks][16], error word, ...
+constexpr int PEER_SIGNAL_WORDS = PEER_ERR_WORD + 64;
+struct PeerArgs {
+    int rank, world;
+    unsigned seq;                          // launch number of the group (same on every rank), counts from 1
+    float scale;                           // applied to the sum (1 = plain sum)
+    long n;                                // fp32 elements of the tensor
+    long shard;                            // elements per rank's shard, a multiple of 8, world * shard >= n
+    float* user;                           // the tensor, 16-byte aligned, reduced in place
+    void* stage_self;                      // this launch's half of my staging buffer
+    void* stage_peer[PEER_MAX_RANKS - 1];  // ... of the other ranks, in rank order (peer-mapped)
+    unsigned* sig_self;                    // my signal block (uncached memory)
+    unsigned* sig_peer[PEER_MAX_RANKS - 1];
+    unsigned long long timeout_ticks;      // bound of every poll, in 100 MHz ticks
+};
+int peer_allreduce_blocks(long n, int max_blocks);
+void peer_allreduce(const PeerArgs& a, int blocks, int bf16_wire, hipStream_t st);
+
 }  // namespace dpa

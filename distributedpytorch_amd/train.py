@@ -187,6 +187,7 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                 meter.update(x.shape[0])
                 guard.step()
             last = float(epoch_loss / num_batches)
+            comm.check_peer()                            # DPA_ALLREDUCE=ipc: no bounded poll of the peer-mapped kernel ran out
             breakdown = {k + "_ms": round(v, 4) for k, v in phases.summary().items()} if cfg.breakdown else {}
             rate = meter.rate()
             print(dmetrics.epoch_line_dp(comm.rank, epoch, last), flush=True)            # DP.py:157
@@ -331,6 +332,8 @@ def run_mp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                 print(dmetrics.epoch_line_mp(epoch, loss), flush=True)                      # MP.py:169-170
                 log.log(kind="mp_epoch", epoch=epoch, loss=float(loss), samples_per_sec=meter.rate() * replicas,
                         stage=stage, ms_per_step=meter.ms_per_step(), **breakdown)
+            if dp_comm is not None:
+                dp_comm.check_peer()
             if cfg.checkpoint:
                 save_checkpoint(cfg.checkpoint, stage_mod, opt, epoch, comm=dp_comm, pipeline_comm=pp_comm,
                                 extra={"stage_bounds": [list(b) for b in bounds], "stages": stages})

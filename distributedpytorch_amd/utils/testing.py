@@ -98,6 +98,7 @@ def dp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, buc
         losses.append(float(loss.detach()))
     torch.save({"losses": losses, "params": {n: p.detach().cpu().clone() for n, p in model.named_parameters()},
                 "buckets": len(dp.buckets), "calls": dp.stats["allreduce_calls"], "opt": opt.state_dict(),
+                "peer_launches": int(comm.peer.launches) if comm.peer is not None else 0,
                 "momentum_numel": 0 if opt.momentum_buf is None else opt.momentum_buf.numel()},
                os.path.join(out_dir, f"final_{global_rank}.pt"))
     comm.barrier()
@@ -188,6 +189,46 @@ def pp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, sta
         from ..checkpoint import save_checkpoint
         save_checkpoint(os.path.join(out_dir, f"ckpt_r{replica}.pt"), stage_mod, opt, 0, comm=dp_comm, pipeline_comm=pp_comm)
     world.barrier()
+    dcomm.destroy_process_group()
+
+
+def peer_worker(local_rank, global_rank, world_size, url, out_dir, backend="gloo_gpu", wire="fp32", sizes=(1003, 21840, 3_000_017)):
+    """All-reduce over hipIpc-mapped peer memory (csrc/peer_allreduce.hip; the environment carries DPA_ALLREDUCE=ipc).
+    "gloo_gpu": every rank on GPU 0 (a peer mapping is then a second mapping of the same HBM: the protocol - slicing,
+    flags, staging halves, chunking - is the one that runs between GPUs); "nccl": one GPU per rank beside the native
+    RCCL communicator.  Writes every rank's results and the inputs' seeds."""
+    os.environ["DPA_GRAD_WIRE"] = wire
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        torch.cuda.set_device(0)
+        device, backend = torch.device("cuda", 0), "gloo"
+    comm = dcomm.init_process_group(backend, url, global_rank, world_size, 180.0, device)
+    out = {"attached": comm.peer is not None, "results": {}, "burst": None, "error_seq": -1}
+    if comm.peer is not None:
+        for n in sizes:
+            g = torch.Generator().manual_seed(1000 * n % 7919 + global_rank)
+            x = torch.randn(n, generator=g)
+            t = None
+            for _ in range(3):                       # the same input three times: launches alternate staging halves
+                t = x.to(device)
+                comm.all_reduce(t)
+            torch.cuda.synchronize()
+            out["results"][n] = t.cpu()
+        # a burst of asynchronous reductions on separate tensors (what the bucket hooks issue during backward)
+        g = torch.Generator().manual_seed(77 + global_rank)
+        xs = [torch.randn(50_000 + 64 * i, generator=g).to(device) for i in range(24)]
+        works = [comm.all_reduce(t, async_op=True) for t in xs]
+        for w in works:
+            w.wait()
+        torch.cuda.synchronize()
+        out["burst"] = torch.stack([t[:1000] for t in xs]).cpu()
+        out["error_seq"] = int(comm.peer.error_seq())
+        out["launches"] = int(comm.peer.launches)
+    torch.save(out, os.path.join(out_dir, f"peer_{global_rank}.pt"))
+    comm.barrier()
+    comm.close()
     dcomm.destroy_process_group()
 
 

@@ -281,3 +281,17 @@ def test_bench_pipeline_resnet152_four_stages():
     pipe = rec["config"]["pipeline"]
     assert len(pipe["stages"]) == 4 and 0.0 <= pipe["bubble_fraction_theory"] < 1.0
     assert all(st["max_memory_allocated_gb"] < 288 for st in pipe["stages"])
+
+
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_peer_mapped_allreduce_over_xgmi(tmp_path, monkeypatch, wire):
+    """The one-kernel all-reduce over hipIpc-mapped peer memory (csrc/peer_allreduce.hip) with one GPU per rank: the
+    mappings are xGMI links here, so this is where its system-scope release / acquire meets real remote memory.  A
+    failed self-test falls back to RCCL on every rank - that would show as `attached` False."""
+    _need(2)
+    import test_gpu_peer_allreduce as P
+    world = min(8, torch.cuda.device_count())
+    monkeypatch.setenv("DPA_ALLREDUCE", "ipc")
+    monkeypatch.setenv("DPA_PEER_CHUNK_MB", "8")
+    launch.spawn(T.peer_worker, [world], 0, args=(f"tcp://127.0.0.1:{T.free_port()}", str(tmp_path), "nccl", wire, P.SIZES))
+    P.check_peer_results(tmp_path, world, wire)
