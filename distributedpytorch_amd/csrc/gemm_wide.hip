@@ -255,10 +255,12 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
     int vmsel = 0;
 
     const int row = kq;                                               // 16-lane row of this lane
-    const bool plain_epi = a.bias == nullptr && a.act == 0 && pre_src == nullptr;
+    const bool twin = a.mode == 0 && a.y_act != nullptr;              // fprop: second output gelu(y) (32 stores per item)
+    const bool plain_epi = a.bias == nullptr && a.act == 0 && pre_src == nullptr && !twin;
 #define WG_EPILOGUE(GENERAL)                                                                      \
     {                                                                                             \
         const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (g.dbg & 1) ? 0u : ybytes, 0x00020000); \
+        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(twin ? a.y_act : a.y, 0, (g.dbg & 1) ? 0u : ybytes, 0x00020000); \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
             const int px = m0 + j * 16 + frow;                                                    \
             unsigned eo[4];                                                                       \
@@ -317,6 +319,13 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
                     v = pack8(f);                                                                 \
                 }                                                                                 \
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, yrs, eo[ip] != ~0u ? eo[ip] * 2u : 0xFFFFFFF0u, 0, 0); \
+                if ((GENERAL) && twin) {   /* second output gelu(y), from the bf16 values just stored (what the GELU's backward sees) */ \
+                    float f[8];                                                                   \
+                    unpack8(v, f);                                                                \
+                    _Pragma("unroll") for (int e = 0; e < 8; ++e) f[e] = gelu_tanh_fast(f[e]);    \
+                    const uint4 t = pack8(f);                                                     \
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{t.x, t.y, t.z, t.w}, trs, eo[ip] != ~0u ? eo[ip] * 2u : 0xFFFFFFF0u, 0, 0); \
+                }                                                                                 \
             }                                                                                     \
         }                                                                                         \
     }
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
         const int k0 = z * g.nks, steps = min(nk, k0 + g.nks) - k0;
         WG_KSTEP(true, WG_WAIT_SEL)
         for (int s = 1; s < steps; ++s) WG_KSTEP(false, WG_WAIT_8)
-        vmsel = g.splitk == 1 ? 1 : 2;
+        vmsel = (g.splitk == 1 && !twin) ? 1 : 2;                    // stores the next item's first K step may leave in flight: 16 or 32
 
         // Both wave groups write their tile out in the SAME barrier interval: waves 0-3 (one barrier ahead) sit out the
         // interval in which waves 4-7 issue their last MFMAs, and waves 4-7 drop back behind afterwards.  Left staggered,
@@ -510,7 +519,8 @@ bool wide_gemm_supported(const ConvArgs& a) {
     if (!(a.R == 1 && a.S == 1 && a.pad == 0 && a.stride == 1)) return false;
     if (a.mode != 0 && a.mode != 1) return false;
     if (a.C % WBK != 0 || a.K % 8 != 0 || a.y == nullptr) return false;
-    if (a.stats != nullptr || a.y_act != nullptr) return false;
+    if (a.stats != nullptr) return false;
+    if (a.y_act != nullptr && (a.mode != 0 || a.act != 0)) return false;      // the GELU twin: forward, linear epilogue
     if (!(a.epi == 0 || (a.mode == 1 && a.epi == 5))) return false;
     const long M = (long)a.N * a.Ho * a.Wo;
     if (M * a.C * 2 >= (1l << 31) || (long)a.K * a.C * 2 >= (1l << 31) || M * a.K >= (1l << 31) - 16) return false;
@@ -532,6 +542,7 @@ bool wide_gemm_eligible(const ConvArgs& a) {
     const long tiles = ((M + 255) / 256) * ((a.K + 255) / 256);
     const int nk = a.C / WBK;
     const int s = choose_splitk(tiles, nk, M * a.K);
+    if (a.y_act != nullptr && s > 1) return false;          // the twin is written by the tile epilogue, not by the split-K fold
     if (min_tiles == 1) return true;
     if (nk < 12) return false;
     if (s > 1 && nk < 96) return false;
@@ -570,6 +581,10 @@ void gemm_wide(const ConvArgs& a, hipStream_t st) {
     const int nk = a.C / WBK;
     const long tiles = (long)g.tiles_m * g.tiles_n;
     g.splitk = choose_splitk(tiles, nk, M * a.K);
+    if (a.y_act != nullptr && g.splitk > 1) {
+        fprintf(stderr, "gemm_wide: the GELU twin is written by the tile epilogue and cannot be combined with split K\n");
+        abort();
+    }
     g.nks = (nk + g.splitk - 1) / g.splitk;
     g.items = (int)(tiles * g.splitk);
     {

@@ -75,8 +75,10 @@ class Attention(nn.Module):
         return ops.dropout_residual(self.c_proj(a), *self._drop.site(1), residual=residual)
 
 
-# opt-in: measured 1 % SLOWER than the elementwise GELU pass it removes (599.0k vs 604.7k tok/s, docs/DESIGN.md §6)
-_GELU_TWIN = os.environ.get("DPA_GELU_TWIN", "0") == "1"
+# Round 2 (8 x 1024 tokens: c_fc on the 128 x 128 kernel): 1 % SLOWER than the elementwise GELU pass it removes (599.0k vs
+# 604.7k tok/s, docs/DESIGN.md §6).  Round 3 (16 x 1024: c_fc is 768 tiles of the 256 x 256 kernel, whose epilogue now
+# writes the twin from registers): measured again, docs/ROUND3.md.  DPA_GELU_TWIN=0/1.
+_GELU_TWIN = os.environ.get("DPA_GELU_TWIN", "1") == "1"
 
 
 class MLP(nn.Module):

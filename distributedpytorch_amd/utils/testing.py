@@ -232,6 +232,19 @@ def peer_worker(local_rank, global_rank, world_size, url, out_dir, backend="gloo
     dcomm.destroy_process_group()
 
 
+def peer_refusal_worker(local_rank, global_rank, world_size, url, out_dir):
+    """CPU ranks ask for the peer-mapped all-reduce: every rank must decline together (one agreement on the control
+    plane) and keep reducing over gloo."""
+    comm = dcomm.init_process_group("gloo", url, global_rank, world_size, 60.0, torch.device("cpu"))
+    comm.attach_peer()
+    t = torch.full((5,), float(global_rank + 1))
+    comm.all_reduce(t)
+    torch.save({"attached": comm.peer is not None, "sum": t}, os.path.join(out_dir, f"refusal_{global_rank}.pt"))
+    comm.check_peer()                       # no layer, nothing to report
+    comm.barrier()
+    dcomm.destroy_process_group()
+
+
 def crash_worker(local_rank, global_rank, world_size, url):
     """Rank 1 dies before the collective; the others would hang forever without the launcher's monitor."""
     comm = dcomm.init_process_group("gloo", url, global_rank, world_size, 120.0, torch.device("cpu"))

@@ -16,6 +16,9 @@ run dp2_r50 2 --batch 32 --steps 4 --warmup 2
 run dp2_gpt2 2 --model gpt2 --batch 2 --steps 4 --warmup 2
 run dp2_mnist 2 --model mnist --steps 50 --warmup 10
 run dp2_r50_sharded 2 --batch 32 --steps 4 --warmup 2 --shard-optimizer
+# gradient buckets through the one-kernel all-reduce over hipIpc-mapped peer memory (two ranks of one GPU map each other)
+DPA_PEER_CHUNK_MB=8 run dp2_r50_ipc 2 --batch 32 --steps 4 --warmup 2 --allreduce ipc
+grep -o '"allreduce": "[^"]*"' gpurun_out/rehearse/dp2_r50_ipc.log | tail -1
 run pp2_mnist 2 --model mnist --pipeline 2 --steps 20 --warmup 5
 run pp4_r152 4 --model resnet152 --pipeline 4 --batch 32 --steps 3 --warmup 1
 # the RCCL path (native communicator, every bucket all-reduced for real) at world size 1

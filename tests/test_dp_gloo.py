@@ -101,3 +101,13 @@ def test_training_loop_options_world2(tmp_path, capfd, extra):
     losses = [float(v) for v in re.findall(r"Rank  0  , epoch  \d+  :  ([0-9.]+)", out)]
     assert len(losses) == 3 and losses[-1] < losses[0], losses
     assert all(json.loads(l)["kind"] == "dp_epoch" for l in open(log))
+
+
+def test_peer_mapped_allreduce_declines_together_without_a_gpu(tmp_path):
+    """Communicator.attach_peer (DPA_ALLREDUCE=ipc, csrc/peer_comm.cpp) on CPU ranks: no GPU, so every rank must fall
+    back TOGETHER - decided on the control plane - and collectives keep working over gloo."""
+    world = 2
+    launch.spawn(T.peer_refusal_worker, [world], 0, args=(f"tcp://127.0.0.1:{T.free_port()}", str(tmp_path)))
+    outs = [torch.load(tmp_path / f"refusal_{r}.pt", weights_only=True) for r in range(world)]
+    assert not any(o["attached"] for o in outs)
+    assert all(torch.equal(o["sum"], torch.full((5,), 3.0)) for o in outs)

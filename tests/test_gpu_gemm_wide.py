@@ -195,3 +195,24 @@ def test_split_k_workspace_comes_from_torchs_caching_allocator():
     assert torch.cuda.memory_allocated() - base <= y.numel() * 2 + (1 << 20)    # ... and it was handed back
     ref = x.float().view(M, K) @ w.float().view(N, K).t()
     assert float((y.view(M, N).float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 128, 264), (4100, 64, 5000), (16384, 768, 3072)])
+def test_wide_gemm_forward_gelu_twin(M, K, N):
+    """fprop with the second output gelu_tanh(y) written by the same epilogue (GPT-2's c_fc: y stays for the GELU's backward,
+    the twin feeds c_proj): both outputs against the 128 x 128 kernel's and against fp32; ragged edges never written."""
+    C = _C()
+    x = _rand((M, 1, 1, K), 1.0, 11)
+    w = _rand((N, 1, 1, K), 0.1, 12)
+    b = (torch.randn(N, generator=torch.Generator().manual_seed(13)) * 0.5).to(DEV)
+    with _Wide(True):
+        y, t = C.conv_fprop(x, w, b, 1, 0, 0, False, None, None, True)
+    with _Wide(False):
+        y0, t0 = C.conv_fprop(x, w, b, 1, 0, 0, False, None, None, True)
+    ref = x.float().view(M, K) @ w.float().view(N, K).t() + b
+    _check(y.view(M, N), ref, y0.view(M, N), f"twin fprop y {M}x{N}x{K}")
+    # the twin is a function of the ROUNDED y: compare against gelu of this kernel's own y
+    want = torch.nn.functional.gelu(y.float(), approximate="tanh")
+    err = (t.float() - want).abs().max().item()
+    assert err <= 8e-3 * float(want.abs().max()) + 1e-3, err
+    _check(t.view(M, N), torch.nn.functional.gelu(ref, approximate="tanh"), t0.view(M, N), f"twin fprop gelu(y) {M}x{N}x{K}")
