@@ -410,7 +410,7 @@ class Communicator:
         communicator).  Collective over this communicator."""
         if self._static is not None:
             key = self._obj_key("xchg")
-            self.store.set_object(f"{key}/{self.rank}", obj)
+            self.store.set_object(f"{key}/{self.rank}", obj, readers=self.world_size)
             return [self.store.get_object(f"{key}/{r}") for r in range(self.world_size)]
         out = [None] * self.world_size
         dist.all_gather_object(out, obj, group=self.group)
@@ -840,7 +840,7 @@ class Communicator:
             return [obj]
         if self._static is not None:
             key = self._obj_key("gather")
-            self.store.set_object(f"{key}/{self.rank}", obj)
+            self.store.set_object(f"{key}/{self.rank}", obj, readers=1)          # read once, by dst: then gone
             if self.rank != dst:
                 return None
             return [self.store.get_object(f"{key}/{r}") for r in range(self.world_size)]
@@ -854,7 +854,7 @@ class Communicator:
         if self._static is not None:
             key = self._obj_key("bcast")
             if self.rank == src:
-                self.store.set_object(key, obj)
+                self.store.set_object(key, obj, readers=self.world_size - 1)
                 return obj
             return self.store.get_object(key)
         box = [obj]

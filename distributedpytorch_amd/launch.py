@@ -105,6 +105,12 @@ def spawn(fn: Callable, gpu_list: Sequence[int] = (1,), node_index: int = 0, arg
     False (call ``.join()`` on it).
     """
     topo = topology(gpu_list, node_index)
+    if len(gpu_list) == 1 and "DPA_STORE_TOKEN" not in os.environ:
+        # one node: the job's ranks are exactly this launcher's children, so a random per-job secret for the rendezvous
+        # store (store.py: requests without it are dropped) can be drawn here and inherited.  Several nodes are started by
+        # hand (multinode-DP/README.md:15-17): export the same DPA_STORE_TOKEN on each of them.
+        import secrets
+        os.environ["DPA_STORE_TOKEN"] = secrets.token_hex(16)
     ctx = mp.get_context(start_method)
     err_queue = ctx.SimpleQueue()
     procs = []
