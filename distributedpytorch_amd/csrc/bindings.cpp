@@ -1122,6 +1122,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("conv3x3_halo_enabled", []() { return dpa::conv3x3_halo_enabled() != 0; });
     m.def("set_wide_gemm_min_tiles", [](int64_t n) { dpa::set_wide_gemm_min_tiles((int)n); });
     m.def("set_wide_gemm_splitk", [](int64_t n) { dpa::set_wide_gemm_splitk((int)n); });
+    m.def("set_wide_gemm_bn", [](int64_t n) { dpa::set_wide_gemm_bn((int)n); });
     m.def("wide_gemm_min_tiles", []() { return (int64_t)dpa::wide_gemm_min_tiles(); });
     bind_transformer(m);
     bind_rccl(m);

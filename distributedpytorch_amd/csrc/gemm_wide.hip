@@ -82,7 +82,17 @@ struct WideArgs {
     int skew;                 // start-up skew: workgroup b sleeps b * skew / 256 periods of 8128 cycles before its first item
 };
 
+// NT = channel tiles (of 16) per wave row: the output tile is 256 pixels x (32 * NT) channels.  NT = 8 is the 256 x 256
+// tile; NT = 6 (256 x 192) exists for tile QUANTISATION: a GEMM with 768 output channels over 16,384 tokens is 192 tiles
+// of 256 x 256 - three quarters of one round on 256 CUs - but exactly 256 tiles of 256 x 192, and 2304 / 3072 channels
+// are 12 / 16 such tiles (whole rounds again).  The LDS image, the DMA plan and every barrier / vmcnt count are those of
+// NT = 8: LDS rows [wr * 128 + 16 * NT, wr * 128 + 128) of the filter tile are simply dead (their DMA pieces point past
+// the operand and write zeros: no memory traffic), phases 3 and 4 of a K step issue 4 * (NT - 4) MFMAs instead of 16.
+template <int NT>
 __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs g) {
+    static_assert(NT == 8 || NT == 6, "wave row = 4 + (NT - 4) channel tiles");
+    constexpr int HALF = 16 * NT;                        // channels per wave row
+    constexpr int BN = 2 * HALF;                         // channels per output tile
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -141,9 +151,10 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
             item_coords(P##_seq, tm_, tn_, z_);                                                   \
             P##_kt = z_ * g.nks;                                                                  \
             P##_kend = min(nk, P##_kt + g.nks);                                                   \
-            const int w0_ = tn_ * 256 + WG_WROW(R, 0) + lrow, w1_ = tn_ * 256 + WG_WROW(R, 1) + lrow; \
-            P##_w0 = w0_ < Nn ? (unsigned)w0_ * (unsigned)Kd * 2u + src_chunk : OOB;              \
-            P##_w1 = w1_ < Nn ? (unsigned)w1_ * (unsigned)Kd * 2u + src_chunk : OOB;              \
+            const int r0_ = WG_WROW(R, 0) + lrow, r1_ = WG_WROW(R, 1) + lrow;     /* LDS rows of the filter tile */ \
+            const int w0_ = tn_ * BN + (r0_ >> 7) * HALF + (r0_ & 127), w1_ = tn_ * BN + (r1_ >> 7) * HALF + (r1_ & 127); \
+            P##_w0 = ((r0_ & 127) < HALF && w0_ < Nn) ? (unsigned)w0_ * (unsigned)Kd * 2u + src_chunk : OOB; \
+            P##_w1 = ((r1_ & 127) < HALF && w1_ < Nn) ? (unsigned)w1_ * (unsigned)Kd * 2u + src_chunk : OOB; \
             const int x0_ = tm_ * 256 + WG_XROW(R, 0) + lrow, x1_ = tm_ * 256 + WG_XROW(R, 1) + lrow; \
             P##_x0 = x0_ < M ? (unsigned)x0_ * (unsigned)Kd * 2u + src_chunk : OOB;               \
             P##_x1 = x1_ < M ? (unsigned)x1_ * (unsigned)Kd * 2u + src_chunk : OOB;               \
@@ -170,12 +181,12 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
     const unsigned char* const wfb = wsm + (wr * 128) * ROWB;
     const unsigned char* const xfb = wsm + TILE_B + (wc * 64) * ROWB;
 
-    floatx4 acc[8][4];
+    floatx4 acc[NT][4];
     bf16x8 wf[4][2], xa[2][2], xb[2][2];
     const floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
 #define WG_READ_W(I0)                                                                             \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) if ((I0) + i < NT) {                            \
         wf[i][0] = *(const bf16x8*)(wp_ + ((I0) + i) * (16 * ROWB) + fo0);                        \
         wf[i][1] = *(const bf16x8*)(wp_ + ((I0) + i) * (16 * ROWB) + fo1);                        \
     }
@@ -187,17 +198,17 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
     // ZERO: first K step of an item - the ks = 0 MFMA starts from the inline constant 0 (no clearing pass)
 #define WG_MMA(I0, J0, XF, ZERO)                                                                  \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) if ((I0) + i < NT)                          \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                         \
                 acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], XF[j][ks], \
                     ((ZERO) && ks == 0) ? zero4 : acc[(I0) + i][(J0) + j], 0, 0, 0);
     // end of a load segment: retire the region the next phase reads, meet, wait for this phase's fragments
 #define WG_WAIT_8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    // first K step of an item: the previous item's epilogue stores (16, or 32 partial-sum stores) may stay in flight
+    // first K step of an item: the previous item's epilogue stores (2 NT, or 4 NT partial-sum / twin stores) may stay in flight
 #define WG_WAIT_SEL()                                                                             \
     if (vmsel == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                              \
-    else if (vmsel == 1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                        \
-    else asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+    else if (vmsel == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + 2 * NT) : "memory");       \
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + 4 * NT) : "memory");
 #define WG_TO_MMA(WAIT)                                                                           \
     WAIT()                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                            \
@@ -263,26 +274,26 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
         const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(twin ? a.y_act : a.y, 0, (g.dbg & 1) ? 0u : ybytes, 0x00020000); \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
             const int px = m0 + j * 16 + frow;                                                    \
-            unsigned eo[4];                                                                       \
-            u32x4 pre[4];                                                                         \
-            unsigned pmk[4];                                                                      \
-            _Pragma("unroll") for (int ip = 0; ip < 4; ++ip) {                                    \
+            unsigned eo[NT / 2];                                                                  \
+            u32x4 pre[NT / 2];                                                                    \
+            unsigned pmk[NT / 2];                                                                 \
+            _Pragma("unroll") for (int ip = 0; ip < NT / 2; ++ip) {                               \
                 const int ch = c0 + 16 * (2 * ip + (row & 1)) + 8 * (row >> 1);                   \
                 eo[ip] = (px < M && ch < Nn) ? (unsigned)px * (unsigned)Nn + (unsigned)ch : ~0u;  \
             }                                                                                     \
             if ((GENERAL) && pre_src != nullptr) {                                                \
                 const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)pre_src, 0, ybytes, 0x00020000); \
-                _Pragma("unroll") for (int ip = 0; ip < 4; ++ip)                                  \
+                _Pragma("unroll") for (int ip = 0; ip < NT / 2; ++ip)                             \
                     pre[ip] = __builtin_amdgcn_raw_buffer_load_b128(srs, eo[ip] != ~0u ? eo[ip] * 2u : 0xFFFFFFF0u, 0, 0); \
                 if (!gelu_bwd && a.addend_mask != nullptr) {                                      \
                     const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.addend_mask, 0, ybytes >> 4, 0x00020000); \
-                    _Pragma("unroll") for (int ip = 0; ip < 4; ++ip)                              \
+                    _Pragma("unroll") for (int ip = 0; ip < NT / 2; ++ip)                         \
                         pmk[ip] = __builtin_amdgcn_raw_buffer_load_b8(mrs, eo[ip] != ~0u ? eo[ip] >> 3 : 0xFFFFFFF0u, 0, 0); \
                 } else {                                                                          \
-                    _Pragma("unroll") for (int ip = 0; ip < 4; ++ip) pmk[ip] = 0xFFu;             \
+                    _Pragma("unroll") for (int ip = 0; ip < NT / 2; ++ip) pmk[ip] = 0xFFu;        \
                 }                                                                                 \
             }                                                                                     \
-            _Pragma("unroll") for (int ip = 0; ip < 4; ++ip) {                                    \
+            _Pragma("unroll") for (int ip = 0; ip < NT / 2; ++ip) {                               \
                 unsigned d[2][2];                                                                 \
                 _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                   \
                     const int i = 2 * ip + h;                                                     \
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
         const int k0 = z * g.nks, steps = min(nk, k0 + g.nks) - k0;
         WG_KSTEP(true, WG_WAIT_SEL)
         for (int s = 1; s < steps; ++s) WG_KSTEP(false, WG_WAIT_8)
-        vmsel = (g.splitk == 1 && !twin) ? 1 : 2;                    // stores the next item's first K step may leave in flight: 16 or 32
+        vmsel = (g.splitk == 1 && !twin) ? 1 : 2;                    // stores the next item's first K step may leave in flight: 2 NT or 4 NT
 
         // Both wave groups write their tile out in the SAME barrier interval: waves 0-3 (one barrier ahead) sit out the
         // interval in which waves 4-7 issue their last MFMAs, and waves 4-7 drop back behind afterwards.  Left staggered,
@@ -344,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
         // the cost per item.
         if (wr == 0) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        const int m0 = tm * 256 + wc * 64, c0 = tn * 256 + wr * 128;
+        const int m0 = tm * 256 + wc * 64, c0 = tn * BN + wr * HALF;
         if (g.splitk > 1) {
             // ---- partial sums: this lane's 4 consecutive channels of a pixel = one 16-byte fp32 store ----
             float* const slab = g.ws + (size_t)z * (size_t)M * (size_t)Nn;
@@ -353,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
             for (int j = 0; j < 4; ++j) {
                 const int px = m0 + j * 16 + frow;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < NT; ++i) {
                     const int ch = c0 + i * 16 + q4;
                     const unsigned off = (px < M && ch < Nn) ? ((unsigned)px * (unsigned)Nn + (unsigned)ch) * 4u : 0xFFFFFFF0u;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), prs, off, 0, 0);
@@ -476,8 +487,9 @@ float* workspace_for(hipStream_t st, size_t bytes) {
 }
 
 // Split factor of a launch: a cost model in microseconds calibrated on scripts/one_gemm.py (1.35 us per K step per
-// workgroup, ~1 us per item, slabs written and read back at ~4 TB/s); 1 = no split.
-int choose_splitk(long tiles, int nk, long MN) {
+// workgroup on the 256 x 256 tile - `kstep_us` - and ~1 us per item, slabs written and read back at ~4 TB/s); 1 = no
+// split.  *model_us receives the modelled time of the choice.
+int choose_splitk(long tiles, int nk, long MN, double kstep_us = 1.35, double* model_us = nullptr) {
     if (g_wide_splitk < 0) {
         const char* e = getenv("DPA_WIDE_SPLITK");
         g_wide_splitk = e ? atoi(e) : 0;
@@ -492,11 +504,39 @@ int choose_splitk(long tiles, int nk, long MN) {
         if (s > 1 && ((long)(s - 1) * nks >= nk || nks < 4)) continue;     // every split non-empty and worth an item
         if (s > 1 && (double)s * MN * 4.0 >= 4.0e9) continue;
         const long rounds = (tiles * s + 255) / 256;
-        double t = rounds * (nks * 1.35 + 1.0);
+        // K ranges of one tile do not share operand panels in L2 the way neighbouring tiles at the SAME K offset do: a split
+        // K step was measured at 1.7 - 2.5 us (LM-head input gradient, 8,192 / 16,384 tokens) against 1.2 - 1.35 unsplit
+        double t = rounds * (nks * kstep_us * (s > 1 ? 1.6 : 1.0) + 1.0);
         if (s > 1) t += (s + 0.5) * MN * 4.0 / 4.0e6;
         if (t < best * 0.97) { best = t; best_s = s; }
     }
+    if (model_us != nullptr) *model_us = best;
     return best_s;
+}
+
+int g_wide_bn = -1;             // -1: not yet read; 0 = choose per launch; 256 / 192 = force
+
+// Tile width (output channels per tile) and split factor of a launch: whichever of 256 x 256 and 256 x 192 the cost model
+// prices lower - the narrow tile's K step is 48 MFMAs per wave instead of 64 but only ~0.9 of the time (measured), so what decides
+// is the number of ROUNDS the tiles make on 256 CUs (768 channels x 16,384 tokens: 0.75 round of wide tiles, one whole
+// round of narrow ones).  DPA_WIDE_BN=256|192 forces one.
+struct WidePlan { int bn, tiles_m, tiles_n, splitk; };
+WidePlan plan_wide(long M, int Nn, int nk) {
+    if (g_wide_bn < 0) {
+        const char* e = getenv("DPA_WIDE_BN");
+        g_wide_bn = e ? atoi(e) : 0;
+        if (g_wide_bn != 192 && g_wide_bn != 256) g_wide_bn = 0;
+    }
+    WidePlan best{};
+    double best_us = 1e30;
+    for (int bn = 256; bn >= 192; bn -= 64) {
+        if (g_wide_bn != 0 && bn != g_wide_bn) continue;
+        WidePlan p{bn, (int)((M + 255) / 256), (Nn + bn - 1) / bn, 1};
+        double us = 0.0;
+        p.splitk = choose_splitk((long)p.tiles_m * p.tiles_n, nk, M * Nn, bn == 256 ? 1.30 : 1.18, &us);
+        if (us < best_us * 0.97) { best_us = us; best = p; }       // (ties go to the wide tile)
+    }
+    return best;
 }
 
 }  // namespace
@@ -506,12 +546,13 @@ void set_wide_gemm_min_tiles(int n) { g_wide_min_tiles = n < 0 ? 0 : n; }
 int wide_gemm_min_tiles() {
     if (g_wide_min_tiles < 0) {
         const char* e = getenv("DPA_WIDE_MIN_TILES");
-        g_wide_min_tiles = e ? atoi(e) : 700;
+        g_wide_min_tiles = e ? atoi(e) : 256;
         if (g_wide_min_tiles < 0) g_wide_min_tiles = 0;
     }
     return g_wide_min_tiles;
 }
 void set_wide_gemm_splitk(int n) { g_wide_splitk = n < 0 ? 0 : n; }
+void set_wide_gemm_bn(int n) { g_wide_bn = (n == 192 || n == 256) ? n : 0; }
 
 // A launch the wide kernel can take: a plain GEMM (1x1, stride 1, no padding) with K a multiple of 64, one of the
 // epilogues implemented above, operands addressable by 31-bit byte offsets.
@@ -529,29 +570,29 @@ bool wide_gemm_supported(const ConvArgs& a) {
 
 // Where the wide kernel wins (scripts/bench_gemm.py, one process, both kernels on the same operands): deep K
 // (>= 768: the per-item cost - a 128-KiB store burst per CU that in-order vmcnt cannot hide - is amortised over >= 12
-// K steps) and enough items to fill the chip; split K only for very deep K (the LM head's input gradient).  The
-// thresholds are lifted by set_wide_gemm_min_tiles(1) (tests: every supported launch).  Default 700 items (about three
-// per workgroup): inside a training step the mid-sized GEMMs (GPT-2's 288-384-tile qkv / fc launches) share the chip
-// with weight-gradient kernels on the side stream, and a persistent kernel with a static, equal share per CU waits
-// for its slowest CU - 84 us in the step against 46 us alone, 593k vs 598k tok/s end to end - so only launches with
-// several items per workgroup (the LM head: 616k vs 599k tok/s) come here.
+// K steps) and a grid that fills WHOLE rounds of the 256 CUs; split K only for very deep K.  The thresholds are lifted
+// by set_wide_gemm_min_tiles(1) (tests: every supported launch).
+// History of the default: 700 items (round 2, batch 8 x 1024: GPT-2's 288-384-tile qkv / fc launches made 1.1-1.5
+// rounds of 256 x 256 tiles, and a persistent one-workgroup-per-CU kernel then runs two full tile times - 621k vs 662k
+// tok/s).  Round 3: with the 256 x 192 tile (plan_wide) the six mid-size GEMMs of a block are whole rounds at 16 x 1024
+// tokens (proj / fc2 / their input gradients: exactly 256 tiles) and run at 0.81-1.25 PFLOP/s alone against 0.63-0.86
+// on the 128 x 128 kernel (profiles/r3/gemm_bench_r3.md); inside the step, one box, interleaved: 789k (700 items) vs
+// 822k tok/s (256 items) at 16 x 1024 and 798k vs 832k at 32 x 1024.  Hence 256: at least one item per CU.
 bool wide_gemm_eligible(const ConvArgs& a) {
     const int min_tiles = wide_gemm_min_tiles();
     if (min_tiles <= 0 || !wide_gemm_supported(a)) return false;
     const long M = (long)a.N * a.Ho * a.Wo;
-    const long tiles = ((M + 255) / 256) * ((a.K + 255) / 256);
     const int nk = a.C / WBK;
-    const int s = choose_splitk(tiles, nk, M * a.K);
+    const WidePlan plan = plan_wide(M, a.K, nk);
+    const long tiles = (long)plan.tiles_m * plan.tiles_n;
+    const int s = plan.splitk;
     if (a.y_act != nullptr && s > 1) return false;          // the twin is written by the tile epilogue, not by the split-K fold
     if (min_tiles == 1) return true;
     if (nk < 12) return false;
     if (s > 1 && nk < 96) return false;
-    // Mid-size launches (GPT-2's qkv / fc: 288-384 tiles) stay on the 128 x 128 kernel although scripts/bench_gemm.py
-    // shows the wide kernel ahead there (46.9 vs 57.6 us for fc 768 -> 3072): that script times launches BACK TO BACK,
-    // and with one 128-KiB workgroup per CU a launch of 1.5 items per workgroup leaves half the CUs idle during its
-    // second round - idle time the NEXT launch of the loop fills.  Inside a step the next kernel depends on this one:
-    // the kernel trace shows 82-89 us per qkv / fc launch (two full tile times) against 46 / 57 us on the 128 x 128
-    // kernel, 621k vs 662k tok/s.  DPA_WIDE_FWD=1 re-creates the experiment.
+    // (scripts/bench_gemm.py times launches BACK TO BACK: the idle CUs of a partial last round are filled by the next
+    // launch of the loop; inside a step the next kernel depends on this one.  DPA_WIDE_FWD=1: forward launches from 192
+    // tiles, the round-2 experiment.)
     static const bool fwd_wide = [] { const char* e = getenv("DPA_WIDE_FWD"); return e && atoi(e) != 0; }();   // experiment switch
     if (fwd_wide && a.mode == 0 && s == 1 && tiles >= 192) return true;
     // enough work for several items per workgroup, counted in tile-K-steps so that the answer does not depend on the
@@ -567,20 +608,23 @@ void gemm_wide(const ConvArgs& a, hipStream_t st) {
     }
     static bool allowed = false;
     if (!allowed) {
-        const hipError_t err = hipFuncSetAttribute((const void*)gemm_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
-        if (err != hipSuccess) {
-            fprintf(stderr, "gemm_wide: cannot allow %d bytes of LDS: %s\n", WIDE_LDS, hipGetErrorString(err));
-            abort();
+        for (const void* fn : {(const void*)gemm_wide_kernel<8>, (const void*)gemm_wide_kernel<6>}) {
+            const hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
+            if (err != hipSuccess) {
+                fprintf(stderr, "gemm_wide: cannot allow %d bytes of LDS: %s\n", WIDE_LDS, hipGetErrorString(err));
+                abort();
+            }
         }
         allowed = true;
     }
     const long M = (long)a.N * a.Ho * a.Wo;
     WideArgs g{};
-    g.tiles_m = (int)((M + 255) / 256); g.tiles_n = (a.K + 255) / 256;
-    g.M = (int)M; g.Kd = a.C;
     const int nk = a.C / WBK;
+    const WidePlan plan = plan_wide(M, a.K, nk);
+    g.tiles_m = plan.tiles_m; g.tiles_n = plan.tiles_n;
+    g.M = (int)M; g.Kd = a.C;
     const long tiles = (long)g.tiles_m * g.tiles_n;
-    g.splitk = choose_splitk(tiles, nk, M * a.K);
+    g.splitk = plan.splitk;
     if (a.y_act != nullptr && g.splitk > 1) {
         fprintf(stderr, "gemm_wide: the GELU twin is written by the tile epilogue and cannot be combined with split K\n");
         abort();
@@ -595,7 +639,8 @@ void gemm_wide(const ConvArgs& a, hipStream_t st) {
     { static const int dbg = [] { const char* e = getenv("DPA_WIDE_DBG"); return e ? atoi(e) : 0; }(); g.dbg = dbg; }
     g.ws = g.splitk > 1 ? workspace_for(st, (size_t)g.splitk * (size_t)M * (size_t)a.K * 4) : nullptr;
     const int grid = g.items < 256 ? g.items : 256;
-    hipLaunchKernelGGL(gemm_wide_kernel, dim3(grid), dim3(512), WIDE_LDS, st, a, g);
+    if (plan.bn == 256) hipLaunchKernelGGL(gemm_wide_kernel<8>, dim3(grid), dim3(512), WIDE_LDS, st, a, g);
+    else                hipLaunchKernelGGL(gemm_wide_kernel<6>, dim3(grid), dim3(512), WIDE_LDS, st, a, g);
     if (g.splitk > 1) {
         const long MN = M * a.K;
         long blocks = (MN / 8 + 255) / 256;

@@ -61,6 +61,7 @@ void gemm_wide(const ConvArgs& a, hipStream_t st);
 void set_wide_gemm_min_tiles(int n);
 void set_wide_gemm_splitk(int n);   // 0 = chosen per launch by a cost model, n > 0 = forced (tests)
 int wide_gemm_min_tiles();
+void set_wide_gemm_bn(int n);       // output channels per tile: 0 = chosen per launch, 256 or 192 = forced (tests, benchmarks)
 // Temporary device memory of the kernels' launchers (gemm_wide's split-K slabs): alloc(bytes, stream) returns a block that
 // may be used by work enqueued on `stream` until free(ptr); the framework registers torch's caching allocator
 typedef void* (*WorkspaceAlloc)(size_t bytes, hipStream_t stream);

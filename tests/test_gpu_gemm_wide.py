@@ -11,6 +11,18 @@ import torch
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
+BN = 256          # output channels per tile forced by _Wide: every test below runs once per tile width (fixture)
+
+
+@pytest.fixture(autouse=True, params=[256, 192], ids=["tile256x256", "tile256x192"])
+def _tile_width(request):
+    """The 256 x 192 variant (template NT = 6) shares the LDS image, DMA plan and barrier structure of the 256 x 256 one;
+    only the dead filter rows, the MFMA count of phases 3-4 and the store counts behind vmcnt differ - so it gets every
+    test the wide tile gets."""
+    global BN
+    BN = request.param
+    yield
+    BN = 256
 
 
 def _C():
@@ -27,19 +39,21 @@ class _Wide:
     """Route every eligible launch to the wide kernel (min items 1) or to the 128 x 128 kernel (0); ``splitk`` > 0
     forces that many K ranges per tile (0: the cost model decides)."""
 
-    def __init__(self, on, splitk=1):
-        self.on, self.splitk = on, splitk
+    def __init__(self, on, splitk=1, bn=None):
+        self.on, self.splitk, self.bn = on, splitk, (BN if bn is None else bn)
 
     def __enter__(self):
         C = _C()
         self.keep = C.wide_gemm_min_tiles()
         C.set_wide_gemm_min_tiles(1 if self.on else 0)
         C.set_wide_gemm_splitk(self.splitk)
+        C.set_wide_gemm_bn(self.bn)
 
     def __exit__(self, *exc):
         C = _C()
         C.set_wide_gemm_min_tiles(self.keep)
         C.set_wide_gemm_splitk(0)
+        C.set_wide_gemm_bn(0)
         return False
 
 
