@@ -392,6 +392,46 @@ void conv_wgrad(const Tensor& x, const Tensor& dy, Tensor& dw, int64_t stride, i
     }
 }
 
+// Weight gradients of several Linear layers over the same tokens in one launch (csrc/wgrad_wide.hip):
+// dw[q] [K,1,1,C] fp32 += dy[q]^T x[q]; dbias[q] (fp32 [K], optional per layer) += column sums of dy[q].
+void wgrad_wide_group(const std::vector<Tensor>& xs, const std::vector<Tensor>& dys, std::vector<Tensor> dws,
+                      const std::vector<c10::optional<Tensor>>& dbiases) {
+    const size_t n = xs.size();
+    TORCH_CHECK(n >= 1 && n <= (size_t)dpa::WGRAD_WIDE_MAX && dys.size() == n && dws.size() == n && dbiases.size() == n,
+                "wgrad_wide_group: 1..", dpa::WGRAD_WIDE_MAX, " layers, one entry per list each");
+    std::vector<dpa::WgradArgs> probs(n);
+    int64_t M = -1;
+    for (size_t q = 0; q < n; ++q) {
+        const Tensor &x = xs[q], &dy = dys[q];
+        Tensor& dw = dws[q];
+        CHECK_BF16(x); CHECK_BF16(dy); CHECK_F32(dw);
+        const int64_t C = x.size(-1), K = dy.size(-1), rows = x.numel() / C;
+        TORCH_CHECK(dy.numel() / K == rows && dw.numel() == K * C, "wgrad_wide_group: layer ", q, " shape mismatch");
+        TORCH_CHECK(M < 0 || rows == M, "wgrad_wide_group: every layer must reduce over the same rows");
+        M = rows;
+        dpa::WgradArgs a{};
+        a.x = x.data_ptr(); a.dy = dy.data_ptr(); a.dw = dw.data_ptr<float>();
+        a.N = (int)rows; a.H = a.W = a.Ho = a.Wo = 1; a.C = (int)C; a.K = (int)K; a.R = a.S = 1; a.stride = 1; a.pad = 0;
+        a.dbias = nullptr;
+        if (dbiases[q].has_value() && dbiases[q]->defined()) {
+            CHECK_F32((*dbiases[q]));
+            TORCH_CHECK(dbiases[q]->numel() == K, "wgrad_wide_group: dbias must have K elements");
+            a.dbias = dbiases[q]->data_ptr<float>();
+        }
+        TORCH_CHECK(dpa::wgrad_wide_supported(a), "wgrad_wide_group: layer ", q, " (", rows, " x ", K, " x ", C, ") is not supported");
+        probs[q] = a;
+    }
+    Guard g(xs[0]);
+    dpa::wgrad_wide_group(probs.data(), (int)n, cur_stream());
+}
+
+// whether conv_wgrad's dispatcher would send this Linear-shaped problem to the wide kernel, and its 256 x 256 tile count
+std::tuple<bool, int64_t> wgrad_wide_query(int64_t rows, int64_t K, int64_t C) {
+    dpa::WgradArgs a{};
+    a.N = (int)rows; a.H = a.W = a.Ho = a.Wo = 1; a.C = (int)C; a.K = (int)K; a.R = a.S = 1; a.stride = 1; a.pad = 0;
+    return {dpa::wgrad_wide_eligible(a), (int64_t)dpa::wgrad_wide_tiles(a)};
+}
+
 Tensor transpose_filter(const Tensor& w) {
     CHECK_BF16(w);
     TORCH_CHECK(w.dim() == 4, "transpose_filter: KRSC expected");
@@ -1056,6 +1096,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("transpose_filters_batched", &transpose_filters_batched);
     m.def("transpose_tile", [] { return dpa::transpose_tile(); });
     m.def("colsum", &colsum);
+    m.def("wgrad_wide_group", &wgrad_wide_group, py::arg("xs"), py::arg("dys"), py::arg("dws"), py::arg("dbiases"));
+    m.def("wgrad_wide_query", &wgrad_wide_query);
+    m.def("set_wgrad_wide_splitk", [](int64_t n) { dpa::set_wgrad_wide_splitk((int)n); });
     m.def("bn_stats", &bn_stats);
     m.def("bn_finalize", &bn_finalize);
     m.def("bn_apply", &bn_apply, py::arg("x"), py::arg("residual"), py::arg("scale"), py::arg("shift"), py::arg("relu"),

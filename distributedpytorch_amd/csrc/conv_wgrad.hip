@@ -403,11 +403,13 @@ bool use_dma(const WgradArgs& a) {
 
 // the bias-gradient variant exists for the Linear-shaped DMA kernels (every GPT-2 projection)
 bool conv_wgrad_fuses_bias(const WgradArgs& a) {
+    if (wgrad_wide_alone_pays(a)) return true;
     const bool lin = a.R == 1 && a.S == 1 && a.pad == 0 && a.stride == 1;
     return lin && use_dma(a);
 }
 
 void conv_wgrad(const WgradArgs& a, hipStream_t st) {
+    if (wgrad_wide_alone_pays(a)) { wgrad_wide_group(&a, 1, st); return; }  // large Linear layers: wgrad_wide.hip (256 x 256 tiles)
     if (conv_wgrad_halo_ok(a)) { conv_wgrad_halo(a, st); return; }     // 3 x 3 on 56- / 28-wide maps: conv_wgrad_halo.hip
     const bool lin = a.R == 1 && a.S == 1 && a.pad == 0 && a.stride == 1;
     const bool dma = use_dma(a);

@@ -650,6 +650,11 @@ void gemm_wide(const ConvArgs& a, hipStream_t st) {
     }
 }
 
+void* launcher_workspace(size_t bytes, hipStream_t st) { return workspace_for(st, bytes); }
+void launcher_workspace_release(void* p) {
+    if (g_ws_alloc != nullptr && g_ws_free != nullptr) g_ws_free(p);      // stream-ordered: reusable behind what was enqueued
+}
+
 void set_workspace_allocator(WorkspaceAlloc alloc, WorkspaceFree free_) {
     g_ws_alloc = alloc;
     g_ws_free = free_;

@@ -93,6 +93,20 @@ void conv_wgrad_halo(const WgradArgs& a, hipStream_t st);
 // true when conv_wgrad's kernel for this problem also produces a.dbias (else the caller runs colsum_bf16)
 bool conv_wgrad_fuses_bias(const WgradArgs& a);
 
+// Wide-tile weight gradient of Linear-shaped problems, several layers over the same tokens in ONE launch
+// (wgrad_wide.hip): 256 x 256 tiles, token split folded in a fixed order (no float atomics on dw).
+constexpr int WGRAD_WIDE_MAX = 8;                    // layers per launch
+bool wgrad_wide_supported(const WgradArgs& a);       // can run there
+bool wgrad_wide_eligible(const WgradArgs& a);        // ... and pays (DPA_WGRAD_WIDE=0: never)
+bool wgrad_wide_alone_pays(const WgradArgs& a);      // ... even in a launch of its own: conv_wgrad() then routes it here
+long wgrad_wide_tiles(const WgradArgs& a);
+void wgrad_wide_group(const WgradArgs* probs, int nprob, hipStream_t st);
+void set_wgrad_wide_splitk(int n);                   // 0 = chosen per launch, n > 0 = forced (tests)
+// temporary device memory of a launcher, usable by work enqueued on `st` until released (the registered allocator, or a
+// grow-only block per stream)
+void* launcher_workspace(size_t bytes, hipStream_t st);
+void launcher_workspace_release(void* p);
+
 // Backward of "1x1 conv (CM -> CO = 4 CM channels) -> BatchNorm -> ReLU mask" in one kernel (tail_bwd.hip):
 //   g = cA * (dout under kout) + cB * craw + cC  (never stored);  dw += g^T xin;  dx = g w;
 //   optionally the reduction pass of the BatchNorm behind dx: stats += (sum dx', sum dx' * sx), dx' = dx under smask

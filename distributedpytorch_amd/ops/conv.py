@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from . import _ext
 from . import side as _side
 from . import sink as _sink
+from . import wgroup as _wgroup
 
 
 def _lp(weight: torch.Tensor, weight_lp: Optional[torch.Tensor]) -> torch.Tensor:
@@ -79,6 +80,17 @@ class _ConvFn(torch.autograd.Function):
         if weight.requires_grad:
             tgt = _sink.target(weight)
             if tgt is not None:     # accumulate straight into the flat grad buffer, off the critical path (ops/side.py)
+                linear_shaped = w.shape[1] == 1 and w.shape[2] == 1 and x.shape[1] == 1 and x.shape[2] == 1 and stride == 1 and pad == 0
+                if (linear_shaped and _wgroup.ENABLED and _side.active(x) and (db_tgt is None or db is None)
+                        and _wgroup.query(x.shape[0], w.shape[0], w.shape[3])[0]):
+                    # a large Linear layer: held back and launched TOGETHER with its neighbours' weight gradients
+                    # (ops/wgroup.py, csrc/wgrad_wide.hip); the batcher reports weight and bias ready when it launches
+                    rows, cout, cin = x.shape[0], w.shape[0], w.shape[3]
+                    _wgroup.for_device(x.device.index).add(
+                        x.view(rows, cin), dy.view(rows, cout), tgt.view(cout, cin), db_tgt,
+                        [weight] + ([bias] if db_tgt is not None else []), _wgroup.query(rows, cout, cin)[1])
+                    return (dx, None, None, None, None, None, None, None, None, None, None,
+                            dy if (ctx.has_residual and ctx.needs_input_grad[11]) else None, None, None, None)
                 if _side.active(x) and (db_tgt is None or db is None):
                     tv = tgt.view(w.shape)
                     _side.run(lambda: C.conv_wgrad(x, dy, tv, stride, pad, db_tgt), (x, dy))

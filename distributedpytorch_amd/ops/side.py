@@ -21,11 +21,26 @@ from __future__ import annotations
 
 import os
 from collections import deque
-from typing import Callable, Deque, Dict, Sequence, Tuple
+from typing import Callable, Deque, Dict, List, Sequence, Tuple
 
 import torch
 
 ENABLED = os.environ.get("DPA_WGRAD_STREAM", "1") != "0"
+
+# Producers that HOLD BACK side-stream launches (ops/wgroup.py collects the weight gradients of several layers for one
+# launch) register a flush here: it runs, with the device index, before anybody joins or borrows the side stream - i.e.
+# before any consumer of a gradient (bucket all-reduce, optimizer, end of backward) can get ahead of a held-back launch.
+_flush_hooks: List[Callable[[int], None]] = []
+
+
+def add_flush_hook(fn: Callable[[int], None]) -> None:
+    if fn not in _flush_hooks:
+        _flush_hooks.append(fn)
+
+
+def _run_flush_hooks(index: int) -> None:
+    for fn in _flush_hooks:
+        fn(index)
 
 
 class SideStream:
@@ -57,6 +72,7 @@ class SideStream:
         return done
 
     def join(self) -> None:
+        _run_flush_hooks(self.index)
         if not self.dirty:
             return
         self.dirty = False
@@ -98,6 +114,7 @@ class on_side_stream:
         self.ctx = None
 
     def __enter__(self):
+        _run_flush_hooks(self.index)
         side = for_device(self.index)
         side.stream.wait_stream(torch.cuda.current_stream(self.index))
         side.dirty = True
@@ -128,3 +145,5 @@ def join(device=None) -> None:
     s = _per_device.get(index)
     if s is not None:
         s.join()
+    else:
+        _run_flush_hooks(index)
