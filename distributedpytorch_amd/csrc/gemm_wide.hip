@@ -62,6 +62,9 @@ constexpr int TILE_B = 256 * ROWB;         // one operand tile: 32 KiB
 constexpr int BUF_B = 2 * TILE_B;          // one K tile: filter rows, then pixel rows
 constexpr int WIDE_LDS = 2 * BUF_B;        // 128 KiB
 constexpr unsigned OOB = 0x80000000u;      // byte offset past every operand (operands are < 2^31 bytes)
+#ifndef WIDE_EPI_JB
+#define WIDE_EPI_JB 1
+#endif
 constexpr int GM = 8;                      // pixel tiles per group of the item order
 
 typedef __attribute__((address_space(3))) unsigned char* lds_byte_ptr;
@@ -88,7 +91,10 @@ struct WideArgs {
 // are 12 / 16 such tiles (whole rounds again).  The LDS image, the DMA plan and every barrier / vmcnt count are those of
 // NT = 8: LDS rows [wr * 128 + 16 * NT, wr * 128 + 128) of the filter tile are simply dead (their DMA pieces point past
 // the operand and write zeros: no memory traffic), phases 3 and 4 of a K step issue 4 * (NT - 4) MFMAs instead of 16.
-template <int NT>
+// GEN: the fused epilogues (bias / activation / residual addend / GELU backward / GELU twin) are compiled in.  The plain
+// tile (LM head, plain input gradients) gets its own instantiation: with both epilogues in one kernel the general one's
+// registers spilled into the plain path as well (fc 768 -> 3072 plain: 76 -> 104 us when the general epilogue grew).
+template <int NT, bool GEN>
 __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs g) {
     static_assert(NT == 8 || NT == 6, "wave row = 4 + (NT - 4) channel tiles");
     constexpr int HALF = 16 * NT;                        // channels per wave row
@@ -266,34 +272,51 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
     int vmsel = 0;
 
     const int row = kq;                                               // 16-lane row of this lane
-    const bool twin = a.mode == 0 && a.y_act != nullptr;              // fprop: second output gelu(y) (32 stores per item)
-    const bool plain_epi = a.bias == nullptr && a.act == 0 && pre_src == nullptr && !twin;
+    const bool twin = GEN && a.mode == 0 && a.y_act != nullptr;       // fprop: second output gelu(y) (32 stores per item)
+    // The fused operands are requested in as few round trips as the ~64 registers freed by the dead fragments allow: the
+    // bias slice of the tile ONCE per item as eight 16-byte loads (it used to be 4 x 32 dword loads per item and lane),
+    // the residual / GELU operand of TWO pixel tiles at a time (two round trips per item instead of four).  Measured on
+    // GPT-2's GEMMs at 16,384 tokens (scripts/bench_gemm.py EPI=1; before -> after in profiles/r3/gemm_epilogue_ab.txt).
+    constexpr int JB = WIDE_EPI_JB;                                    // pixel tiles whose fused operands are requested together
 #define WG_EPILOGUE(GENERAL)                                                                      \
     {                                                                                             \
         const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (g.dbg & 1) ? 0u : ybytes, 0x00020000); \
         const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(twin ? a.y_act : a.y, 0, (g.dbg & 1) ? 0u : ybytes, 0x00020000); \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
-            const int px = m0 + j * 16 + frow;                                                    \
-            unsigned eo[NT / 2];                                                                  \
-            u32x4 pre[NT / 2];                                                                    \
-            unsigned pmk[NT / 2];                                                                 \
-            _Pragma("unroll") for (int ip = 0; ip < NT / 2; ++ip) {                               \
-                const int ch = c0 + 16 * (2 * ip + (row & 1)) + 8 * (row >> 1);                   \
-                eo[ip] = (px < M && ch < Nn) ? (unsigned)px * (unsigned)Nn + (unsigned)ch : ~0u;  \
+        _Pragma("unroll") for (int jh = 0; jh < 4 / JB; ++jh) {                                        \
+            unsigned eo[JB][NT / 2];                                                               \
+            u32x4 pre[JB][NT / 2];                                                                 \
+            unsigned pmk[JB][NT / 2];                                                              \
+            floatx4 bias4[NT];     /* the tile's bias slice: eight 16-byte loads (L1 hits after the first pixel tile) */ \
+            if ((GENERAL) && a.bias != nullptr) {                                                 \
+                const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, (unsigned)Nn * 4u, 0x00020000); \
+                _Pragma("unroll") for (int i = 0; i < NT; ++i)    /* (Nn % 8 == 0: 4 channels are in range together) */ \
+                    bias4[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(brs, (unsigned)(c0 + i * 16 + q4) * 4u, 0, 0)); \
+            }                                                                                     \
+            _Pragma("unroll") for (int jj = 0; jj < JB; ++jj) {                                    \
+                const int px = m0 + (jh * JB + jj) * 16 + frow;                                    \
+                _Pragma("unroll") for (int ip = 0; ip < NT / 2; ++ip) {                           \
+                    const int ch = c0 + 16 * (2 * ip + (row & 1)) + 8 * (row >> 1);               \
+                    eo[jj][ip] = (px < M && ch < Nn) ? (unsigned)px * (unsigned)Nn + (unsigned)ch : ~0u; \
+                }                                                                                 \
             }                                                                                     \
             if ((GENERAL) && pre_src != nullptr) {                                                \
                 const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)pre_src, 0, ybytes, 0x00020000); \
-                _Pragma("unroll") for (int ip = 0; ip < NT / 2; ++ip)                             \
-                    pre[ip] = __builtin_amdgcn_raw_buffer_load_b128(srs, eo[ip] != ~0u ? eo[ip] * 2u : 0xFFFFFFF0u, 0, 0); \
+                _Pragma("unroll") for (int jj = 0; jj < JB; ++jj)                                  \
+                    _Pragma("unroll") for (int ip = 0; ip < NT / 2; ++ip)                         \
+                        pre[jj][ip] = __builtin_amdgcn_raw_buffer_load_b128(srs, eo[jj][ip] != ~0u ? eo[jj][ip] * 2u : 0xFFFFFFF0u, 0, 0); \
                 if (!gelu_bwd && a.addend_mask != nullptr) {                                      \
                     const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.addend_mask, 0, ybytes >> 4, 0x00020000); \
-                    _Pragma("unroll") for (int ip = 0; ip < NT / 2; ++ip)                         \
-                        pmk[ip] = __builtin_amdgcn_raw_buffer_load_b8(mrs, eo[ip] != ~0u ? eo[ip] >> 3 : 0xFFFFFFF0u, 0, 0); \
+                    _Pragma("unroll") for (int jj = 0; jj < JB; ++jj)                              \
+                        _Pragma("unroll") for (int ip = 0; ip < NT / 2; ++ip)                     \
+                            pmk[jj][ip] = __builtin_amdgcn_raw_buffer_load_b8(mrs, eo[jj][ip] != ~0u ? eo[jj][ip] >> 3 : 0xFFFFFFF0u, 0, 0); \
                 } else {                                                                          \
-                    _Pragma("unroll") for (int ip = 0; ip < NT / 2; ++ip) pmk[ip] = 0xFFu;        \
+                    _Pragma("unroll") for (int jj = 0; jj < JB; ++jj)                              \
+                        _Pragma("unroll") for (int ip = 0; ip < NT / 2; ++ip) pmk[jj][ip] = 0xFFu; \
                 }                                                                                 \
             }                                                                                     \
+            _Pragma("unroll") for (int jj = 0; jj < JB; ++jj)                                      \
             _Pragma("unroll") for (int ip = 0; ip < NT / 2; ++ip) {                               \
+                const int j = jh * JB + jj;                                                        \
                 unsigned d[2][2];                                                                 \
                 _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                   \
                     const int i = 2 * ip + h;                                                     \
@@ -301,8 +324,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
                     _Pragma("unroll") for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];            \
                     if (GENERAL) {                                                                \
                         if (a.bias != nullptr) {                                                  \
-                            const int ch = c0 + i * 16 + q4;                                      \
-                            _Pragma("unroll") for (int r = 0; r < 4; ++r) v[r] += a.bias[min(ch + r, Nn - 1)]; \
+                            _Pragma("unroll") for (int r = 0; r < 4; ++r) v[r] += bias4[i][r];    \
                         }                                                                         \
                         if (a.act == 1) {                                                         \
                             _Pragma("unroll") for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); \
@@ -320,22 +342,23 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
                 uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);                                 \
                 if ((GENERAL) && pre_src != nullptr) {                                            \
                     float f[8], gx[8];                                                            \
-                    unpack8(v, f); unpack8(__builtin_bit_cast(uint4, pre[ip]), gx);               \
+                    unpack8(v, f); unpack8(__builtin_bit_cast(uint4, pre[jj][ip]), gx);           \
                     if (gelu_bwd) {                                                               \
                         _Pragma("unroll") for (int e = 0; e < 8; ++e) f[e] *= gelu_tanh_grad_fast(gx[e]); \
                     } else {                                                                      \
-                        const unsigned mk = pmk[ip];                                              \
+                        const unsigned mk = pmk[jj][ip];                                          \
                         _Pragma("unroll") for (int e = 0; e < 8; ++e) f[e] += ((mk >> e) & 1u) ? gx[e] : 0.f; \
                     }                                                                             \
                     v = pack8(f);                                                                 \
                 }                                                                                 \
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, yrs, eo[ip] != ~0u ? eo[ip] * 2u : 0xFFFFFFF0u, 0, 0); \
+                const unsigned so_ = eo[jj][ip] != ~0u ? eo[jj][ip] * 2u : 0xFFFFFFF0u;           \
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, yrs, so_, 0, 0); \
                 if ((GENERAL) && twin) {   /* second output gelu(y), from the bf16 values just stored (what the GELU's backward sees) */ \
                     float f[8];                                                                   \
                     unpack8(v, f);                                                                \
                     _Pragma("unroll") for (int e = 0; e < 8; ++e) f[e] = gelu_tanh_fast(f[e]);    \
                     const uint4 t = pack8(f);                                                     \
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{t.x, t.y, t.z, t.w}, trs, eo[ip] != ~0u ? eo[ip] * 2u : 0xFFFFFFF0u, 0, 0); \
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{t.x, t.y, t.z, t.w}, trs, so_, 0, 0); \
                 }                                                                                 \
             }                                                                                     \
         }                                                                                         \
@@ -374,8 +397,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
         // ---- epilogue from registers: bias / activation in fp32, pack, pair adjacent channel tiles so that a
         //      lane holds 8 consecutive channels: 16 range-checked 16-byte stores per lane, no branches.
         //      Expanded once for the plain tile (BatchNorm-free GEMMs: the LM head) and once in general form ----
-        if (plain_epi) WG_EPILOGUE(false)
-        else           WG_EPILOGUE(true)
+        WG_EPILOGUE(GEN)
         __builtin_amdgcn_sched_barrier(0);
         if (wr == 1) __builtin_amdgcn_s_barrier();
     }
@@ -489,7 +511,7 @@ float* workspace_for(hipStream_t st, size_t bytes) {
 // Split factor of a launch: a cost model in microseconds calibrated on scripts/one_gemm.py (1.35 us per K step per
 // workgroup on the 256 x 256 tile - `kstep_us` - and ~1 us per item, slabs written and read back at ~4 TB/s); 1 = no
 // split.  *model_us receives the modelled time of the choice.
-int choose_splitk(long tiles, int nk, long MN, double kstep_us = 1.35, double* model_us = nullptr) {
+int choose_splitk(long tiles, int nk, long MN, double kstep_us = 1.35, double* model_us = nullptr, double item_us = 1.0) {
     if (g_wide_splitk < 0) {
         const char* e = getenv("DPA_WIDE_SPLITK");
         g_wide_splitk = e ? atoi(e) : 0;
@@ -506,7 +528,7 @@ int choose_splitk(long tiles, int nk, long MN, double kstep_us = 1.35, double* m
         const long rounds = (tiles * s + 255) / 256;
         // K ranges of one tile do not share operand panels in L2 the way neighbouring tiles at the SAME K offset do: a split
         // K step was measured at 1.7 - 2.5 us (LM-head input gradient, 8,192 / 16,384 tokens) against 1.2 - 1.35 unsplit
-        double t = rounds * (nks * kstep_us * (s > 1 ? 1.6 : 1.0) + 1.0);
+        double t = rounds * (nks * kstep_us * (s > 1 ? 1.6 : 1.0) + (s > 1 ? 1.0 : item_us));
         if (s > 1) t += (s + 0.5) * MN * 4.0 / 4.0e6;
         if (t < best * 0.97) { best = t; best_s = s; }
     }
@@ -520,8 +542,12 @@ int g_wide_bn = -1;             // -1: not yet read; 0 = choose per launch; 256 
 // prices lower - the narrow tile's K step is 48 MFMAs per wave instead of 64 but only ~0.9 of the time (measured), so what decides
 // is the number of ROUNDS the tiles make on 256 CUs (768 channels x 16,384 tokens: 0.75 round of wide tiles, one whole
 // round of narrow ones).  DPA_WIDE_BN=256|192 forces one.
+// `epi`: 0 = plain tile, 1 = bias / activation, 2 = a second operand or output (residual, GELU backward, GELU twin).  The
+// fused epilogue of the 256-wide tile runs out of registers (128 accumulators + the operands in flight: spill code whose
+// scratch accesses drain vmcnt) and costs about twice the narrow tile's per item - measured at 16,384 tokens, K = 768:
+// bias +8.4 vs +3.4 us per item, residual +17 vs +6.5, GELU backward +18.6 vs +9.3 (profiles/r3/gemm_epilogue_ab.txt).
 struct WidePlan { int bn, tiles_m, tiles_n, splitk; };
-WidePlan plan_wide(long M, int Nn, int nk) {
+WidePlan plan_wide(long M, int Nn, int nk, int epi) {
     if (g_wide_bn < 0) {
         const char* e = getenv("DPA_WIDE_BN");
         g_wide_bn = e ? atoi(e) : 0;
@@ -533,7 +559,8 @@ WidePlan plan_wide(long M, int Nn, int nk) {
         if (g_wide_bn != 0 && bn != g_wide_bn) continue;
         WidePlan p{bn, (int)((M + 255) / 256), (Nn + bn - 1) / bn, 1};
         double us = 0.0;
-        p.splitk = choose_splitk((long)p.tiles_m * p.tiles_n, nk, M * Nn, bn == 256 ? 1.30 : 1.18, &us);
+        const double item_us = 1.0 + (epi == 0 ? 0.0 : epi == 1 ? (bn == 256 ? 8.0 : 3.5) : (bn == 256 ? 17.0 : 8.0));
+        p.splitk = choose_splitk((long)p.tiles_m * p.tiles_n, nk, M * Nn, bn == 256 ? 1.30 : 1.18, &us, item_us);
         if (us < best_us * 0.97) { best_us = us; best = p; }       // (ties go to the wide tile)
     }
     return best;
@@ -578,12 +605,18 @@ bool wide_gemm_supported(const ConvArgs& a) {
 // tokens (proj / fc2 / their input gradients: exactly 256 tiles) and run at 0.81-1.25 PFLOP/s alone against 0.63-0.86
 // on the 128 x 128 kernel (profiles/r3/gemm_bench_r3.md); inside the step, one box, interleaved: 789k (700 items) vs
 // 822k tok/s (256 items) at 16 x 1024 and 798k vs 832k at 32 x 1024.  Hence 256: at least one item per CU.
+int wide_epilogue_kind(const ConvArgs& a) {
+    const bool gelu_bwd = a.mode == 1 && a.epi == 5;
+    if (a.y_act != nullptr || (gelu_bwd ? a.ep_src : a.addend) != nullptr) return 2;
+    return (a.bias != nullptr || a.act != 0) ? 1 : 0;
+}
+
 bool wide_gemm_eligible(const ConvArgs& a) {
     const int min_tiles = wide_gemm_min_tiles();
     if (min_tiles <= 0 || !wide_gemm_supported(a)) return false;
     const long M = (long)a.N * a.Ho * a.Wo;
     const int nk = a.C / WBK;
-    const WidePlan plan = plan_wide(M, a.K, nk);
+    const WidePlan plan = plan_wide(M, a.K, nk, wide_epilogue_kind(a));
     const long tiles = (long)plan.tiles_m * plan.tiles_n;
     const int s = plan.splitk;
     if (a.y_act != nullptr && s > 1) return false;          // the twin is written by the tile epilogue, not by the split-K fold
@@ -608,7 +641,8 @@ void gemm_wide(const ConvArgs& a, hipStream_t st) {
     }
     static bool allowed = false;
     if (!allowed) {
-        for (const void* fn : {(const void*)gemm_wide_kernel<8>, (const void*)gemm_wide_kernel<6>}) {
+        for (const void* fn : {(const void*)gemm_wide_kernel<8, false>, (const void*)gemm_wide_kernel<6, false>,
+                               (const void*)gemm_wide_kernel<8, true>, (const void*)gemm_wide_kernel<6, true>}) {
             const hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
             if (err != hipSuccess) {
                 fprintf(stderr, "gemm_wide: cannot allow %d bytes of LDS: %s\n", WIDE_LDS, hipGetErrorString(err));
@@ -620,7 +654,7 @@ void gemm_wide(const ConvArgs& a, hipStream_t st) {
     const long M = (long)a.N * a.Ho * a.Wo;
     WideArgs g{};
     const int nk = a.C / WBK;
-    const WidePlan plan = plan_wide(M, a.K, nk);
+    const WidePlan plan = plan_wide(M, a.K, nk, wide_epilogue_kind(a));
     g.tiles_m = plan.tiles_m; g.tiles_n = plan.tiles_n;
     g.M = (int)M; g.Kd = a.C;
     const long tiles = (long)g.tiles_m * g.tiles_n;
@@ -639,8 +673,14 @@ void gemm_wide(const ConvArgs& a, hipStream_t st) {
     { static const int dbg = [] { const char* e = getenv("DPA_WIDE_DBG"); return e ? atoi(e) : 0; }(); g.dbg = dbg; }
     g.ws = g.splitk > 1 ? workspace_for(st, (size_t)g.splitk * (size_t)M * (size_t)a.K * 4) : nullptr;
     const int grid = g.items < 256 ? g.items : 256;
-    if (plan.bn == 256) hipLaunchKernelGGL(gemm_wide_kernel<8>, dim3(grid), dim3(512), WIDE_LDS, st, a, g);
-    else                hipLaunchKernelGGL(gemm_wide_kernel<6>, dim3(grid), dim3(512), WIDE_LDS, st, a, g);
+    const bool plain = wide_epilogue_kind(a) == 0;
+    if (plan.bn == 256) {
+        if (plain) hipLaunchKernelGGL((gemm_wide_kernel<8, false>), dim3(grid), dim3(512), WIDE_LDS, st, a, g);
+        else       hipLaunchKernelGGL((gemm_wide_kernel<8, true>), dim3(grid), dim3(512), WIDE_LDS, st, a, g);
+    } else {
+        if (plain) hipLaunchKernelGGL((gemm_wide_kernel<6, false>), dim3(grid), dim3(512), WIDE_LDS, st, a, g);
+        else       hipLaunchKernelGGL((gemm_wide_kernel<6, true>), dim3(grid), dim3(512), WIDE_LDS, st, a, g);
+    }
     if (g.splitk > 1) {
         const long MN = M * a.K;
         long blocks = (MN / 8 + 255) / 256;

@@ -39,6 +39,9 @@ class _ConvFn(torch.autograd.Function):
                 residual=None, pre_gelu=False, gelu_twin=False, gelu_act=None):
         C = _ext.load()
         w = _lp(weight, weight_lp).view(wshape)   # KRSC view (a Linear weight [out,in] is K,1,1,C)
+        # the second output (statistics / GELU twin) is not differentiable: without this autograd hands backward a
+        # ZERO-FILLED tensor of its shape - a 100 MB fill kernel per GPT-2 block (seen in the kernel trace)
+        ctx.set_materialize_grads(False)
         ctx.pre_gelu = pre_gelu
         if pre_gelu:                              # y = layer(gelu(x)): the GELU's backward rides the dgrad epilogue
             ctx.gelu_in = x
@@ -63,6 +66,8 @@ class _ConvFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         stride, pad, act = ctx.geom
         assert act == 0, "fused activation epilogues are forward-only"
+        if dy is None:                            # (materialize_grads is off) nothing flows back through this layer
+            return (None,) * 15
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:

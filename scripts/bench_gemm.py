@@ -37,6 +37,18 @@ for name, m, K_in, N_out in SHAPES:
             "128  fprop": (0, lambda: C.conv_fprop(x, w, None, 1, 0, 0, False, None)),
             "wide dgrad": (1, lambda: C.conv_dgrad(dy, wt, 1, 1, 1, 0, None, None)),
             "128  dgrad": (0, lambda: C.conv_dgrad(dy, wt, 1, 1, 1, 0, None, None))}
+    if os.environ.get("EPI") == "1":
+        # the fused epilogues GPT-2 uses on these shapes (wide kernel): bias / bias + residual / bias + GELU twin / GELU backward
+        bias = torch.randn(N_out, device="cuda")
+        res = torch.randn(m, 1, 1, N_out, device="cuda").to(torch.bfloat16)
+        h = torch.randn(m, 1, 1, K_in, device="cuda").to(torch.bfloat16)
+        arms = {"wide plain": (1, lambda: C.conv_fprop(x, w, None, 1, 0, 0, False, None)),
+                "wide bias": (1, lambda: C.conv_fprop(x, w, bias, 1, 0, 0, False, None)),
+                "wide bias+res": (1, lambda: C.conv_fprop(x, w, bias, 1, 0, 0, False, None, res)),
+                "wide bias+twin": (1, lambda: C.conv_fprop(x, w, bias, 1, 0, 0, False, None, None, True)),
+                "wide dgrad": (1, lambda: C.conv_dgrad(dy, wt, 1, 1, 1, 0, None, None)),
+                "wide dgrad*gelu'": (1, lambda: C.conv_dgrad(dy, wt, 1, 1, 1, 0, None, None, None, None, None, h)),
+                "gelu kernel (N)": (1, lambda: C.ew2(res, res, 3))}
     if WITH_LIB:
         x2, w2, dy2 = x.view(m, K_in), w.view(N_out, K_in), dy.view(m, N_out)
         arms["lib  fprop"] = (0, lambda: torch.matmul(x2, w2.t()))
