@@ -113,3 +113,44 @@ def test_without_bias_and_eligibility_query():
     assert ok and tiles == 27
     ok, _ = C.wgrad_wide_query(16384, 64, 256)           # a ResNet-sized filter stays on conv_wgrad.hip
     assert not ok
+
+
+def test_grouped_weight_gradients_through_the_dp_engine_match_per_layer_launches():
+    """ops/wgroup.py in its real place: a GPT-2 with 256-wide blocks over 2,048 tokens through DataParallel with small
+    buckets (bucket launches must flush held-back groups and see every gradient), with a second backward accumulated
+    under no_sync.  Against the same model with the batching off (each layer through conv_wgrad): the gradients may
+    differ by summation order only.  Also: the batcher really launched groups, and left nothing behind."""
+    from distributedpytorch_amd.models import gpt2
+    from distributedpytorch_amd.ops import wgroup
+    from distributedpytorch_amd.parallel.dp import DataParallel
+
+    def grads(batching):
+        keep = wgroup.ENABLED
+        wgroup.ENABLED = batching
+        try:
+            torch.manual_seed(11)
+            m = gpt2.gpt2_tiny(n_layer=3, n_embd=256, n_head=4, vocab=504, n_positions=512).to(DEV).train()
+            g = torch.Generator(device=DEV).manual_seed(5)
+            x = torch.randint(0, 504, (4, 512), generator=g, device=DEV)
+            y = torch.randint(0, 504, (4, 512), generator=g, device=DEV)
+            dp = DataParallel(m, bucket_mb=0.5, first_bucket_mb=0.1)
+            assert len(dp.buckets) >= 3
+            b = wgroup.for_device(torch.cuda.current_device())
+            before = (b.launches, b.problems)
+            with dp.no_sync():
+                m.loss(x, y).backward()
+            m.loss(x, y).backward()
+            dp.finish()
+            torch.cuda.synchronize()
+            assert not b.items, "a held-back weight gradient survived finish()"
+            return dp.flat.grad.clone(), (b.launches - before[0], b.problems - before[1])
+        finally:
+            wgroup.ENABLED = keep
+
+    g1, (launches, problems) = grads(True)
+    g0, (l0, p0) = grads(False)
+    assert l0 == 0 and p0 == 0
+    # two backwards x (three blocks x four Linear layers + the LM head), several layers per launch
+    assert problems == 2 * (3 * 4 + 1) and 2 <= launches < problems // 2, (launches, problems)
+    scale = float(g0.abs().max())
+    assert float((g1 - g0).abs().max()) <= 2e-3 * scale, (float((g1 - g0).abs().max()), scale)
