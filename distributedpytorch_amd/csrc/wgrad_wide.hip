@@ -453,6 +453,8 @@ void set_wgrad_wide_splitk(int n) { g_ww_splitk = n < 0 ? 0 : n; }
 bool wgrad_wide_supported(const WgradArgs& a) {
     if (!(a.R == 1 && a.S == 1 && a.pad == 0 && a.stride == 1 && a.asym == 0)) return false;
     if (a.K % 8 != 0 || a.C % 8 != 0) return false;
+    // 16-byte accesses everywhere (DMA chunks, float4 read-modify-write of dw); a shape-only query passes null pointers
+    if (((uintptr_t)a.x | (uintptr_t)a.dy | (uintptr_t)a.dw) % 16 != 0) return false;
     const long M = (long)a.N * a.Ho * a.Wo;
     const long wide = a.K > a.C ? a.K : a.C;
     if ((M + 2 * WBK) * wide * 2 >= (1l << 31)) return false;

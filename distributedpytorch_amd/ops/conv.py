@@ -87,7 +87,8 @@ class _ConvFn(torch.autograd.Function):
             if tgt is not None:     # accumulate straight into the flat grad buffer, off the critical path (ops/side.py)
                 linear_shaped = w.shape[1] == 1 and w.shape[2] == 1 and x.shape[1] == 1 and x.shape[2] == 1 and stride == 1 and pad == 0
                 if (linear_shaped and _wgroup.ENABLED and _side.active(x) and (db_tgt is None or db is None)
-                        and _wgroup.query(x.shape[0], w.shape[0], w.shape[3])[0]):
+                        and _wgroup.query(x.shape[0], w.shape[0], w.shape[3])[0]
+                        and (x.data_ptr() | dy.data_ptr() | tgt.data_ptr()) % 16 == 0):
                     # a large Linear layer: held back and launched TOGETHER with its neighbours' weight gradients
                     # (ops/wgroup.py, csrc/wgrad_wide.hip); the batcher reports weight and bias ready when it launches
                     rows, cout, cin = x.shape[0], w.shape[0], w.shape[3]
