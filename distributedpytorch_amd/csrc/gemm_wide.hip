@@ -94,7 +94,13 @@ struct WideArgs {
 // GEN: the fused epilogues (bias / activation / residual addend / GELU backward / GELU twin) are compiled in.  The plain
 // tile (LM head, plain input gradients) gets its own instantiation: with both epilogues in one kernel the general one's
 // registers spilled into the plain path as well (fc 768 -> 3072 plain: 76 -> 104 us when the general epilogue grew).
-template <int NT, bool GEN>
+// PREW: the filter fragments of channel tiles 0-3 are read ONE PHASE EARLIER - in phase 4 of the previous K step, which
+// has no fragment reads of its own - into a second register set.  The four phases then read 4 / 4 / 8 / 8 fragments instead
+// of 12 / 4 / 8 / 0: with one wave per SIMD in its load segment at a time, 12 x 1 KiB reads x 4 SIMDs are 384 LDS cycles
+// against the 256 cycles of the MFMA segment they must hide behind; 8 are exactly 256.  (Legal under the refill
+// discipline: filter region 0 of step k + 1 is retired by the vmcnt at the end of phase 3 of step k, read in phase 4, and
+// refilled by the DMA of step k + 1's phase 3.)  Costs 32 registers: plain tiles only.
+template <int NT, bool GEN, bool PREW>
 __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs g) {
     static_assert(NT == 8 || NT == 6, "wave row = 4 + (NT - 4) channel tiles");
     constexpr int HALF = 16 * NT;                        // channels per wave row
@@ -188,26 +194,28 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
     const unsigned char* const xfb = wsm + TILE_B + (wc * 64) * ROWB;
 
     floatx4 acc[NT][4];
-    bf16x8 wf[4][2], xa[2][2], xb[2][2];
+    bf16x8 wf[4][2], wf0[PREW ? 4 : 1][2], xa[2][2], xb[2][2];
     const floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-#define WG_READ_W(I0)                                                                             \
+#define WG_READ_WS(WF, WP, I0)                                                                    \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) if ((I0) + i < NT) {                            \
-        wf[i][0] = *(const bf16x8*)(wp_ + ((I0) + i) * (16 * ROWB) + fo0);                        \
-        wf[i][1] = *(const bf16x8*)(wp_ + ((I0) + i) * (16 * ROWB) + fo1);                        \
+        WF[i][0] = *(const bf16x8*)((WP) + ((I0) + i) * (16 * ROWB) + fo0);                       \
+        WF[i][1] = *(const bf16x8*)((WP) + ((I0) + i) * (16 * ROWB) + fo1);                       \
     }
+#define WG_READ_W(I0) WG_READ_WS(wf, wp_, I0)
 #define WG_READ_X(XF, J0)                                                                         \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
         XF[j][0] = *(const bf16x8*)(xp_ + ((J0) + j) * (16 * ROWB) + fo0);                        \
         XF[j][1] = *(const bf16x8*)(xp_ + ((J0) + j) * (16 * ROWB) + fo1);                        \
     }
     // ZERO: first K step of an item - the ks = 0 MFMA starts from the inline constant 0 (no clearing pass)
-#define WG_MMA(I0, J0, XF, ZERO)                                                                  \
+#define WG_MMAS(WF, I0, J0, XF, ZERO)                                                             \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) if ((I0) + i < NT)                          \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                         \
-                acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], XF[j][ks], \
+                acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i][ks], XF[j][ks], \
                     ((ZERO) && ks == 0) ? zero4 : acc[(I0) + i][(J0) + j], 0, 0, 0);
+#define WG_MMA(I0, J0, XF, ZERO) WG_MMAS(wf, I0, J0, XF, ZERO)
     // end of a load segment: retire the region the next phase reads, meet, wait for this phase's fragments
 #define WG_WAIT_8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     // first K step of an item: the previous item's epilogue stores (2 NT, or 4 NT partial-sum / twin stores) may stay in flight
@@ -232,21 +240,23 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
     {                                                                                             \
         const unsigned char* const wp_ = wfb + rpar * BUF_B;                                      \
         const unsigned char* const xp_ = xfb + rpar * BUF_B;                                      \
-        WG_READ_W(0) WG_READ_X(xa, 0)                                                             \
+        if constexpr (!PREW) { WG_READ_W(0) }                                                     \
+        WG_READ_X(xa, 0)                                                                          \
         WG_DMA_X1()                                                                               \
         WG_TO_MMA(VM)                                                                             \
-        WG_MMA(0, 0, xa, ZERO)                                                                    \
+        if constexpr (PREW) { WG_MMAS(wf0, 0, 0, xa, ZERO) } else { WG_MMA(0, 0, xa, ZERO) }      \
         WG_TO_LOAD()                                                                              \
         WG_READ_X(xb, 2)                                                                          \
         WG_DMA_W1()                                                                               \
         WG_TO_MMA(VM)                                                                             \
-        WG_MMA(0, 2, xb, ZERO)                                                                    \
+        if constexpr (PREW) { WG_MMAS(wf0, 0, 2, xb, ZERO) } else { WG_MMA(0, 2, xb, ZERO) }      \
         WG_TO_LOAD()                                                                              \
         WG_READ_W(4)                                                                              \
         WG_DMA_W0()                                                                               \
         WG_TO_MMA(VM)                                                                             \
         WG_MMA(4, 2, xb, ZERO)                                                                    \
         WG_TO_LOAD()                                                                              \
+        if constexpr (PREW) { WG_READ_WS(wf0, wfb + (rpar ^ 1u) * BUF_B, 0) }  /* tiles 0-3 of the NEXT K step */ \
         WG_DMA_X0()                                                                               \
         WG_TO_MMA(VM)                                                                             \
         WG_MMA(4, 0, xa, ZERO)                                                                    \
@@ -263,6 +273,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // filter region 0 and pixel region 0 of step 0 have landed
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();           // waves 4-7 run one barrier behind
+    if constexpr (PREW) { WG_READ_WS(wf0, wfb, 0) }      // tiles 0-3 of step 0 (every later step: phase 4 of its predecessor)
 
     const bool gelu_bwd = a.mode == 1 && a.epi == 5;
     const void* pre_src = gelu_bwd ? a.ep_src : a.addend;
@@ -420,6 +431,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(ConvArgs a, WideArgs 
 #undef WG_DMA_X0
 #undef WG_DMA_X1
 #undef WG_READ_W
+#undef WG_READ_WS
+#undef WG_MMAS
 #undef WG_READ_X
 #undef WG_MMA
 #undef WG_TO_MMA
@@ -641,8 +654,9 @@ void gemm_wide(const ConvArgs& a, hipStream_t st) {
     }
     static bool allowed = false;
     if (!allowed) {
-        for (const void* fn : {(const void*)gemm_wide_kernel<8, false>, (const void*)gemm_wide_kernel<6, false>,
-                               (const void*)gemm_wide_kernel<8, true>, (const void*)gemm_wide_kernel<6, true>}) {
+        for (const void* fn : {(const void*)gemm_wide_kernel<8, false, false>, (const void*)gemm_wide_kernel<6, false, false>,
+                               (const void*)gemm_wide_kernel<8, false, true>, (const void*)gemm_wide_kernel<6, false, true>,
+                               (const void*)gemm_wide_kernel<8, true, false>, (const void*)gemm_wide_kernel<6, true, false>}) {
             const hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
             if (err != hipSuccess) {
                 fprintf(stderr, "gemm_wide: cannot allow %d bytes of LDS: %s\n", WIDE_LDS, hipGetErrorString(err));
@@ -674,13 +688,16 @@ void gemm_wide(const ConvArgs& a, hipStream_t st) {
     g.ws = g.splitk > 1 ? workspace_for(st, (size_t)g.splitk * (size_t)M * (size_t)a.K * 4) : nullptr;
     const int grid = g.items < 256 ? g.items : 256;
     const bool plain = wide_epilogue_kind(a) == 0;
+    // measured: LM-head forward 1166 -> 1148 us, every other shape and the GPT-2 step within noise (profiles/r3/gemm_prew_ab.txt):
+    // the load segment is not bound by its LDS read volume.  Off by default.
+    static const int prew = [] { const char* e = getenv("DPA_WIDE_PREW"); return e ? atoi(e) : 0; }();
+#define WG_LAUNCH(NT_, GEN_, PREW_) hipLaunchKernelGGL((gemm_wide_kernel<NT_, GEN_, PREW_>), dim3(grid), dim3(512), WIDE_LDS, st, a, g)
     if (plan.bn == 256) {
-        if (plain) hipLaunchKernelGGL((gemm_wide_kernel<8, false>), dim3(grid), dim3(512), WIDE_LDS, st, a, g);
-        else       hipLaunchKernelGGL((gemm_wide_kernel<8, true>), dim3(grid), dim3(512), WIDE_LDS, st, a, g);
+        if (!plain) WG_LAUNCH(8, true, false); else if (prew) WG_LAUNCH(8, false, true); else WG_LAUNCH(8, false, false);
     } else {
-        if (plain) hipLaunchKernelGGL((gemm_wide_kernel<6, false>), dim3(grid), dim3(512), WIDE_LDS, st, a, g);
-        else       hipLaunchKernelGGL((gemm_wide_kernel<6, true>), dim3(grid), dim3(512), WIDE_LDS, st, a, g);
+        if (!plain) WG_LAUNCH(6, true, false); else if (prew) WG_LAUNCH(6, false, true); else WG_LAUNCH(6, false, false);
     }
+#undef WG_LAUNCH
     if (g.splitk > 1) {
         const long MN = M * a.K;
         long blocks = (MN / 8 + 255) / 256;
