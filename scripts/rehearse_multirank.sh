@@ -36,3 +36,9 @@ grep -i 'init complete\|init start\|commInitRank' gpurun_out/rehearse/rccl1_init
 DPA_FORCE_COLLECTIVES=1 DPA_COMM_SELFTEST_TIMEOUT=0 timeout -k 10 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 \
     --master-port $((29500 + RANDOM % 400)) bench.py --gpus 1 --model tiny_resnet --batch 32 --steps 5 --warmup 2 > gpurun_out/rehearse/rccl1_fallback.log 2>&1 || { tail -15 gpurun_out/rehearse/rccl1_fallback.log; exit 1; }
 echo "rccl1_fallback: $(grep -o '"comm_layer": "[^"]*"' gpurun_out/rehearse/rccl1_fallback.log | tail -1) $(grep -c 'falling back to c10d' gpurun_out/rehearse/rccl1_fallback.log) fallback notice(s)"
+# GPT-2 over the real RCCL call path at world size 1: the weight-gradient batcher (ops/wgroup.py) feeding buckets that are
+# all-reduced for real, optimizer overlapped with backward
+DPA_FORCE_COLLECTIVES=1 timeout -k 10 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 \
+    --master-port $((29500 + RANDOM % 400)) bench.py --gpus 1 --model gpt2 --steps 10 --warmup 3 > gpurun_out/rehearse/rccl1_gpt2.log 2>&1 || { tail -15 gpurun_out/rehearse/rccl1_gpt2.log; exit 1; }
+echo "rccl1_gpt2 $(grep '^{' gpurun_out/rehearse/rccl1_gpt2.log | tail -1 | cut -c1-150)"
+grep -o '"allreduce_calls_per_step": [0-9.]*' gpurun_out/rehearse/rccl1_gpt2.log | tail -1
