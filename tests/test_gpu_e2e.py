@@ -298,14 +298,25 @@ def test_optimizer_overlapped_with_backward_follows_the_same_trajectory(which):
         assert float(dp.flat.grad.abs().max()) == 0.0                     # every gradient consumed and zeroed
         return losses, dp.flat.master.clone(), opt.momentum_buf.clone()
 
-    l0, p0, m0 = run(False)
-    l1, p1, m1 = run(True)
-    # float atomics in the weight-gradient kernels make two runs differ in the last bits; the trajectories must agree
-    # as closely as two PLAIN runs do
-    l2, p2, m2 = run(False)
-    ref = float((p0 - p2).abs().max())
-    assert float((p0 - p1).abs().max()) <= max(10 * ref, 1e-5), (float((p0 - p1).abs().max()), ref)
-    assert max(abs(a - b) for a, b in zip(l0, l1)) <= max(10 * max(abs(a - b) for a, b in zip(l0, l2)), 1e-3)
+    # The comparison runs in DETERMINISTIC mode (no float atomics: csrc/runtime.hip), where the overlapped and the plain
+    # step must agree bit for bit - same arithmetic, only earlier.  With the default atomic kernels two PLAIN runs of this
+    # tiny model land on one of a few discrete trajectories (a sum that differs in its last bit flips one bf16 rounding;
+    # BatchNorm amplifies it: parameter distance 1e-7 three times out of four, 2e-4 .. 1e-3 otherwise -
+    # scripts/flaky_overlap.py), so "as close as two plain runs" was a coin that came up tails in one run out of six.
+    import distributedpytorch_amd as dpa
+    dpa.set_deterministic(True)
+    try:
+        l0, p0, m0 = run(False)
+        l1, p1, m1 = run(True)
+    finally:
+        dpa.set_deterministic(False)
+    assert torch.equal(p0, p1), float((p0 - p1).abs().max())
+    assert torch.equal(m0, m1), float((m0 - m1).abs().max())
+    assert l0 == l1
+    # ... and with the default (atomic) kernels the overlapped step stays on one of those trajectories
+    l2, p2, m2 = run(True)
+    assert float((p0 - p2).abs().max()) <= 5e-3, float((p0 - p2).abs().max())
+    assert max(abs(a - b) for a, b in zip(l0, l2)) <= 5e-3
 
 
 def test_mnist_hipgraph_step_matches_eager_and_draws_fresh_masks():
