@@ -438,7 +438,9 @@ class Communicator:
                 raise RuntimeError(f"{self.world_size} ranks > {C.PEER_MAX_RANKS} (one xGMI node)")
             index = self.device.index if self.device.index is not None else torch.cuda.current_device()
             peer = C.PeerAllReduce(self.rank, self.world_size, index, _PEER_CHUNK_MB << 20, _PEER_BLOCKS, _PEER_TIMEOUT_S)
-            mine = peer.handles()
+            import secrets
+            # third entry: a random epoch base for the sequence numbers; every rank adopts rank 0's (csrc/peer_comm.cpp set_base)
+            mine = tuple(peer.handles()) + ((1 << 20) + secrets.randbits(30),)
         except Exception as e:  # noqa: BLE001
             ok, why, mine = False, f"{type(e).__name__}: {e}", None
         everyone = self._exchange(mine)
@@ -446,7 +448,8 @@ class Communicator:
             ok, why = False, "another rank could not allocate / export its buffers"
         if ok:
             try:
-                peer.open([(bytes(a), bytes(b)) for a, b in everyone])
+                peer.open([(bytes(h[0]), bytes(h[1])) for h in everyone])
+                peer.set_base(int(everyone[0][2]))
             except Exception as e:  # noqa: BLE001 - e.g. GPUs without peer access, a handle from another node
                 ok, why = False, f"{type(e).__name__}: {e}"
         if not self._agree(ok):

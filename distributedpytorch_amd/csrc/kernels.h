@@ -288,6 +288,7 @@ constexpr int PEER_MAX_RANKS = 8;          // one xGMI-connected node
 constexpr int PEER_MAX_BLOCKS = 64;        // workgroups of one launch = rows of the signal arrays
 constexpr int PEER_ERR_WORD = 2 * PEER_MAX_BLOCKS * 16;       // signal block: A[blocks][16], B[blocks][16], error word, ...
 constexpr int PEER_SIGNAL_WORDS = PEER_ERR_WORD + 64;
+constexpr unsigned PEER_SEQ_WINDOW = 1u << 20;  // a slot value counts as "raised" only within this many launches above the awaited one
 struct PeerArgs {
     int rank, world;
     unsigned seq;                          // launch number of the group (same on every rank), counts from 1

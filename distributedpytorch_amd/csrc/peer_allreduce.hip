@@ -24,7 +24,12 @@
 // (__syncthreads), one lane releases (buffer_wbl2: my dirty L2 lines reach HBM, where the links read), then lanes
 // 0..W-1 each raise my slot in one peer's signal block with a system-scope store and poll that peer's slot in mine
 // (signal memory is uncached fine-grained memory: hipDeviceMallocUncached), then one acquire (buffer_inv) before any
-// lane loads.  Slots hold the launch sequence number, which only grows: no reset pass, no ABA.
+// lane loads.  Slots hold the launch sequence number, which only grows: no reset pass, no ABA.  Sequence numbers start at
+// a random EPOCH BASE drawn per communicator group (peer_comm.cpp set_base) and a poll accepts a slot only inside a window
+// of 2^20 launches above the number it waits for: the protocol does not depend on what the signal memory held before.
+// (It did, once: a second job on the same GPU found slot values of the job before it - larger than its own first sequence
+// numbers - although the block is zeroed at allocation; its polls passed at once, one rank copied a shard that had not
+// been reduced yet and the other waited for a flag that had been "seen" already: profiles/r3/peer_shared_gpu_flake.txt.)
 // The staging buffer has two halves used by alternate launches: rank p may still be reading my half of launch k in
 // its phase 2 when I enter launch k + 1 (which fills the other half); it cannot be later than that, because my
 // barrier B of launch k + 1 needs its flag, which it raises after ITS phase 1 of k + 1.
@@ -60,7 +65,7 @@ __device__ __forceinline__ void peer_barrier(const PeerArgs& a, int which) {
             st_sys(a.sig_peer[tid] + off + a.rank, a.seq);
             const unsigned* mine = a.sig_self + off + p;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while ((int)(ld_sys(mine) - a.seq) < 0) {
+            while ((unsigned)(ld_sys(mine) - a.seq) >= PEER_SEQ_WINDOW) {       // not this epoch's number, or not yet raised
                 if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
                     st_sys(a.sig_self + PEER_ERR_WORD, a.seq);  // host-visible: rank p never arrived at this barrier
                     st_sys(a.sig_self + PEER_ERR_WORD + 1, (unsigned)((which << 16) | ((int)blockIdx.x << 8) | p));

@@ -183,12 +183,23 @@ class PeerAllReduce {
         pending_.clear();
     }
 
-    // launch number at which a bounded poll of this rank last ran out (0 = never): a peer was missing from a barrier
+    // Sequence numbers of this group start at `base` (the same random number on every rank, agreed over the control
+    // plane before the first collective): slot values of an EARLIER job that may survive in the signal memory are outside
+    // the acceptance window of this one (peer_allreduce.hip).  Call once, before the first all_reduce.
+    void set_base(int64_t base) {
+        TORCH_CHECK(seq_ == 0 && base_ == 0, "PeerAllReduce.set_base: once, before the first collective");
+        TORCH_CHECK(base >= (int64_t)dpa::PEER_SEQ_WINDOW && base < (int64_t)0x7fffffff, "PeerAllReduce.set_base: 2^20 <= base < 2^31");
+        base_ = seq_ = (unsigned)base;
+    }
+
+    // launch number (counted from 1) at which a bounded poll of this rank last ran out (0 = never): a peer was missing
+    // from a barrier.  Only a word written in THIS epoch counts.
     int64_t error_seq() {
         c10::hip::HIPGuardMasqueradingAsCUDA guard(dev());
         unsigned v = 0;
         PEER_HIP_CHECK(hipMemcpy(&v, signal_ + dpa::PEER_ERR_WORD, sizeof(v), hipMemcpyDeviceToHost));
-        return (int64_t)v;
+        const unsigned d = v - base_;
+        return (v != 0 && d >= 1 && d < dpa::PEER_SEQ_WINDOW) ? (int64_t)d : 0;
     }
 
     // (barrier << 16 | block << 8 | missing rank) of that poll
@@ -217,7 +228,7 @@ class PeerAllReduce {
         PEER_HIP_CHECK(hipDeviceSynchronize());
     }
 
-    int64_t launches() const { return (int64_t)seq_; }
+    int64_t launches() const { return (int64_t)(seq_ - base_); }
     int rank() const { return rank_; }
     int world_size() const { return world_; }
     int64_t chunk_elems() const { return chunk_elems_; }
@@ -235,7 +246,7 @@ class PeerAllReduce {
     std::vector<void*> peer_stage_;
     std::vector<unsigned*> peer_signal_;
     bool opened_ = false;
-    unsigned seq_ = 0;
+    unsigned seq_ = 0, base_ = 0;
     at::cuda::CUDAEvent ready_{hipEventDisableTiming};
     std::map<int64_t, std::unique_ptr<at::cuda::CUDAEvent>> pending_;
     int64_t next_ticket_ = 1;
@@ -254,6 +265,7 @@ void bind_peer(pybind11::module_& m) {
         .def("wait", &PeerAllReduce::wait)
         .def("query", &PeerAllReduce::query)
         .def("synchronize", &PeerAllReduce::synchronize)
+        .def("set_base", &PeerAllReduce::set_base)
         .def("error_seq", &PeerAllReduce::error_seq)
         .def("error_detail", &PeerAllReduce::error_detail)
         .def("debug_read", &PeerAllReduce::debug_read)
