@@ -14,13 +14,32 @@ from ..parallel.flat import FlatParams
 from ..parallel.pp import PipelineStage, build_stage_module, partition_balanced, param_costs
 
 
+_ports_handed_out = set()
+
+
 def free_port() -> int:
+    """A port for a rendezvous server that is started a moment later by ANOTHER process.  Not ``bind(0)``: that answers
+    with a port of the kernel's ephemeral range (32768-60999 here), which the outgoing connections of the test before -
+    gloo pairs, store clients - draw from too; between this probe and the server's ``listen`` one of them took the port
+    once in ~700 spawns (EADDRINUSE in the GPU tier).  So: a random port BELOW the ephemeral range that binds now, and
+    never the same one twice in a process."""
+    import random
     import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
+    rng = random.Random()
+    for _ in range(200):
+        port = rng.randrange(20000, 32000)
+        if port in _ports_handed_out:
+            continue
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", port))
+        except OSError:
+            continue
+        finally:
+            s.close()
+        _ports_handed_out.add(port)
+        return port
+    raise RuntimeError("no free rendezvous port between 20000 and 32000")
 
 
 def _make_model(name: str):
