@@ -21,6 +21,7 @@ import os
 from . import _ext
 from . import side as _side
 from . import sink as _sink
+from . import wgroup as _wgroup
 
 ENABLED = os.environ.get("DPA_NO_FUSED_BLOCK", "0") != "1"
 # Optional: conv3 + bn3 RECOMPUTED instead of stored when conv3's output is at least DPA_RECOMPUTE_MB big.
@@ -33,6 +34,8 @@ ENABLED = os.environ.get("DPA_NO_FUSED_BLOCK", "0") != "1"
 # is as good a streamer as norm.hip.
 RECOMPUTE_MIN_BYTES = int(float(os.environ.get("DPA_RECOMPUTE_MB", "1e12")) * 2 ** 20)
 _DS_SIDE = os.environ.get("DPA_DS_SIDE", "1") != "0"
+# weight gradients of the late stages' 1 x 1 layers through the wide multi-layer kernel (A/B in profiles/r3/wgrad_wide_resnet_ab.txt)
+_WIDE_1X1 = os.environ.get("DPA_WGRAD_WIDE_1X1", "1") == "1"
 _FOLD_DS_APPLY = os.environ.get("DPA_NO_FOLD_DS_APPLY", "0") != "1"
 
 
@@ -156,6 +159,16 @@ def need_dx_early(ctx) -> bool:
 def _wgrad(C, conv, x, dy, grads, slot, in_line=False):
     tgt = _sink.target(conv.weight)
     if tgt is not None:
+        if (_WIDE_1X1 and not in_line and _wgroup.ENABLED and _side.active(x) and conv.weight.shape[1] == 1 and conv.weight.shape[2] == 1
+                and conv.stride == 1 and conv.padding == 0):
+            # the 1 x 1 layers of the late stages (filters of at least 192 x 192): several blocks' weight gradients in
+            # ONE launch of the wide kernel (ops/wgroup.py, csrc/wgrad_wide.hip)
+            rows, cin, cout = x.numel() // x.shape[-1], x.shape[-1], dy.shape[-1]
+            ok, tiles = _wgroup.query(rows, cout, cin)
+            if ok and (x.data_ptr() | dy.data_ptr() | tgt.data_ptr()) % 16 == 0:
+                _wgroup.for_device(x.device.index).add(x.view(rows, cin), dy.view(rows, cout), tgt.view(cout, cin), None,
+                                                       [conv.weight], tiles)
+                return
         if _side.active(x) and not in_line:   # off the critical path: overlaps the BN-backward / dgrad chain (ops/side.py)
             _side.run(lambda: C.conv_wgrad(x, dy, tgt, conv.stride, conv.padding), (x, dy))
         else:

@@ -154,3 +154,39 @@ def test_grouped_weight_gradients_through_the_dp_engine_match_per_layer_launches
     assert problems == 2 * (3 * 4 + 1) and 2 <= launches < problems // 2, (launches, problems)
     scale = float(g0.abs().max())
     assert float((g1 - g0).abs().max()) <= 2e-3 * scale, (float((g1 - g0).abs().max()), scale)
+
+
+def test_resnet_late_stage_1x1_weight_gradients_go_through_the_batcher():
+    """ops/block.py hands the 1 x 1 layers of the late stages (filters >= 192 x 192, >= 2,048 pixels) to the batcher: with
+    ResNet-50 at batch 16 that is stage 3 (3,136 pixels; stage 4's 7 x 7 maps have 784 and stay).  Same gradients as the per-layer
+    launches of conv_wgrad up to summation order, in aggregate (BatchNorm amplifies the atomics' last-bit noise)."""
+    from distributedpytorch_amd.models import resnet
+    from distributedpytorch_amd.ops import block, wgroup
+    from distributedpytorch_amd.parallel.dp import DataParallel
+
+    def grads(wide):
+        keep = block._WIDE_1X1
+        block._WIDE_1X1 = wide
+        try:
+            torch.manual_seed(21)
+            m = resnet.resnet50().to(DEV).train()
+            g = torch.Generator(device=DEV).manual_seed(9)
+            x = torch.randn(16, 3, 224, 224, generator=g, device=DEV)
+            y = torch.randint(0, 1000, (16,), generator=g, device=DEV)
+            dp = DataParallel(m)
+            b = wgroup.for_device(torch.cuda.current_device())
+            before = b.problems
+            m.loss(x, y).backward()
+            dp.finish()
+            torch.cuda.synchronize()
+            assert not b.items
+            return dp.flat.grad.clone(), b.problems - before
+        finally:
+            block._WIDE_1X1 = keep
+
+    g1, n1 = grads(True)
+    g0, n0 = grads(False)
+    # stage 3: six blocks x (conv1, conv3), and conv1 of stage 4's first block (it still sees the 14 x 14 map)
+    assert n0 == 0 and n1 == 13, (n0, n1)
+    rel = float((g1 - g0).norm() / g0.norm())
+    assert rel < 2e-2, rel
