@@ -67,6 +67,7 @@ struct WwProb {
     const void* dy; const void* x; float* dw; float* dbias;
     int N, K;                 // dw [N][K]; dy [M][N]; x [M][K]
     int tiles_n, tiles_k;
+    int tile0, ntiles;        // the tiles [tile0, tile0 + ntiles) of the layer (n tile major) belong to this launch
     int item0;                // first item of this layer in the launch's item order
 };
 
@@ -85,6 +86,7 @@ __device__ __forceinline__ WwProb pick_prob(ww_args_ptr gp, int pi) {
     WwProb r;
     r.dy = gp->p[pi].dy; r.x = gp->p[pi].x; r.dw = gp->p[pi].dw; r.dbias = gp->p[pi].dbias;
     r.N = gp->p[pi].N; r.K = gp->p[pi].K; r.tiles_n = gp->p[pi].tiles_n; r.tiles_k = gp->p[pi].tiles_k;
+    r.tile0 = gp->p[pi].tile0; r.ntiles = gp->p[pi].ntiles;
     r.item0 = gp->p[pi].item0;
     return r;
 }
@@ -118,9 +120,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_wide_kernel(WwArgs) {
         for (int q = 1; q < WGRAD_WIDE_MAX; ++q)
             if (q < g.nprob && L >= gp->p[q].item0) pi = q;
         const WwProb pr = pick_prob(gp, pi);
-        const int l = L - pr.item0, tiles = pr.tiles_n * pr.tiles_k;
-        z = l / tiles;
-        const int t = l - z * tiles;
+        const int l = L - pr.item0;
+        z = l / pr.ntiles;
+        const int t = pr.tile0 + (l - z * pr.ntiles);
         tn = t / pr.tiles_k; tk = t - tn * pr.tiles_k;
     };
 
@@ -390,21 +392,21 @@ __global__ __launch_bounds__(256) void wgrad_wide_fold_kernel(WwArgs, int total_
 #pragma unroll
         for (int q = 0; q < WGRAD_WIDE_MAX; ++q) {
             if (q < g.nprob) {
-                const int t = gp->p[q].tiles_n * gp->p[q].tiles_k;
+                const int t = gp->p[q].ntiles;
                 if (T >= acc_t) { pi = q; tbase = acc_t; }
                 acc_t += t;
             }
         }
     }
     const WwProb pr = pick_prob(gp, pi);
-    const int tiles = pr.tiles_n * pr.tiles_k, t = T - tbase;
+    const int tiles = pr.ntiles, tl = T - tbase, t = pr.tile0 + tl;
     const int tn = t / pr.tiles_k, tk = t - tn * pr.tiles_k;
     const int e = part * 256 + threadIdx.x;              // 16-byte element of the tile in register order
     const int ij = e >> 9, tid = e & 511;
     const int i = ij >> 2, j = ij & 3;
     const int wave = tid >> 6, lane = tid & 63, wr = wave >> 2, wc = wave & 3, gi = lane >> 4, li = lane & 15;
     const int n = tn * 256 + wr * 128 + i * 16 + li, k = tk * 256 + wc * 64 + j * 16 + gi * 4;
-    const float* src = g.slab + ((long)pr.item0 + t) * TILE_F + (long)e * 4;
+    const float* src = g.slab + ((long)pr.item0 + tl) * TILE_F + (long)e * 4;
     float4 s = *(const float4*)src;
     for (int z = 1; z < g.splitk; ++z) {
         const float4 v = *(const float4*)(src + (long)z * tiles * TILE_F);
@@ -483,6 +485,31 @@ bool wgrad_wide_alone_pays(const WgradArgs& a) {
     return wgrad_wide_tiles(a) * (s < 1 ? 1 : s) >= 192;
 }
 
+namespace {
+
+// one launch over the tile ranges in g.p[0 .. nprob) (tile0 / ntiles filled in), token split `splitk` (0 = choose)
+void launch_ranges(WwArgs& g, double dw_bytes, int splitk, hipStream_t st) {
+    long tiles = 0;
+    for (int q = 0; q < g.nprob; ++q) tiles += g.p[q].ntiles;
+    g.splitk = splitk > 0 ? splitk : choose_split(tiles, g.nk, dw_bytes);
+    g.nks = (g.nk + g.splitk - 1) / g.splitk;
+    int item0 = 0;
+    for (int q = 0; q < g.nprob; ++q) {
+        g.p[q].item0 = item0;
+        item0 += g.p[q].ntiles * g.splitk;
+    }
+    g.items = item0;
+    g.slab = g.splitk > 1 ? (float*)launcher_workspace((size_t)g.items * TILE_F * 4, st) : nullptr;
+    const int grid = g.items < 256 ? g.items : 256;
+    hipLaunchKernelGGL(wgrad_wide_kernel, dim3(grid), dim3(512), WW_LDS, st, g);
+    if (g.splitk > 1) {
+        hipLaunchKernelGGL(wgrad_wide_fold_kernel, dim3((unsigned)(tiles * 64)), dim3(256), 0, st, g, (int)tiles);
+        launcher_workspace_release(g.slab);
+    }
+}
+
+}  // namespace
+
 void wgrad_wide_group(const WgradArgs* probs, int nprob, hipStream_t st) {
     if (nprob < 1 || nprob > WGRAD_WIDE_MAX) {
         fprintf(stderr, "wgrad_wide_group: %d layers in one launch (1..%d)\n", nprob, WGRAD_WIDE_MAX);
@@ -511,25 +538,38 @@ void wgrad_wide_group(const WgradArgs* probs, int nprob, hipStream_t st) {
         p.dy = a.dy; p.x = a.x; p.dw = a.dw; p.dbias = a.dbias;
         p.N = a.K; p.K = a.C;                        // WgradArgs: K = out channels (rows of dw), C = in channels
         p.tiles_n = (a.K + 255) / 256; p.tiles_k = (a.C + 255) / 256;
-        tiles += (long)p.tiles_n * p.tiles_k;
+        p.tile0 = 0; p.ntiles = p.tiles_n * p.tiles_k;
+        tiles += p.ntiles;
         dw_bytes += (double)a.K * a.C * 4.0;
     }
     g.nprob = nprob; g.M = (int)M; g.nk = (int)((M + WBK - 1) / WBK);
-    g.splitk = choose_split(tiles, g.nk, dw_bytes);
-    g.nks = (g.nk + g.splitk - 1) / g.splitk;
-    int item0 = 0;
-    for (int q = 0; q < nprob; ++q) {
-        g.p[q].item0 = item0;
-        item0 += g.p[q].tiles_n * g.p[q].tiles_k * g.splitk;
+    // More tiles than CUs and a ragged last round (the LM head: 591 tiles = 2.3 rounds): the whole rounds run UNSPLIT - each
+    // tile added into dw by its one writer - and only the remaining tiles are split over the tokens, in a second launch
+    // (591 tiles, 16,384 tokens: 512 x 256 K steps + 79 x 3 x 86 instead of 591 x 3 x 86 with 3 x the slab traffic).
+    static const int hybrid = [] { const char* e = getenv("DPA_WGRAD_WIDE_HYBRID"); return e ? atoi(e) : 1; }();
+    if (g_ww_splitk < 0) (void)choose_split(1, 8, 0.0);      // reads DPA_WGRAD_WIDE_SPLITK once
+    const long full = (tiles / 256) * 256, rest = tiles - full;
+    if (hybrid && g_ww_splitk <= 0 && full > 0 && rest > 0 && rest < 224) {
+        WwArgs head = g, tail = g;
+        long left = full;
+        int nh = 0, nt = 0;
+        for (int q = 0; q < nprob; ++q) {
+            const int n = g.p[q].ntiles;
+            const int take = (int)(left < n ? left : n);
+            if (take > 0) { head.p[nh] = g.p[q]; head.p[nh].tile0 = 0; head.p[nh].ntiles = take; ++nh; }
+            if (take < n) {
+                tail.p[nt] = g.p[q]; tail.p[nt].tile0 = take; tail.p[nt].ntiles = n - take;
+                // the bias sums of a layer are produced by the items of its first k tile: once, in whichever launch holds them
+                ++nt;
+            }
+            left -= take;
+        }
+        head.nprob = nh; tail.nprob = nt;
+        launch_ranges(head, dw_bytes, 1, st);
+        launch_ranges(tail, dw_bytes * (double)rest / (double)tiles, 0, st);
+        return;
     }
-    g.items = item0;
-    g.slab = g.splitk > 1 ? (float*)launcher_workspace((size_t)g.items * TILE_F * 4, st) : nullptr;
-    const int grid = g.items < 256 ? g.items : 256;
-    hipLaunchKernelGGL(wgrad_wide_kernel, dim3(grid), dim3(512), WW_LDS, st, g);
-    if (g.splitk > 1) {
-        hipLaunchKernelGGL(wgrad_wide_fold_kernel, dim3((unsigned)(tiles * 64)), dim3(256), 0, st, g, (int)tiles);
-        launcher_workspace_release(g.slab);
-    }
+    launch_ranges(g, dw_bytes, 0, st);
 }
 
 }  // namespace dpa

@@ -105,6 +105,17 @@ def test_more_items_than_workgroups_walks_item_seams():
     _check(dw, rw, "dw 1536x5120x4104 split 2")
 
 
+def test_ragged_last_round_runs_whole_rounds_unsplit_and_splits_the_rest():
+    """600 tiles with the split left to the launcher: 512 tiles in one unsplit launch (each tile's one writer adds it into
+    dw), the other 88 in a second launch split over the tokens (slab + ordered fold); every tile - and every bias sum -
+    exactly once.  Two layers, so that the cut between the launches falls INSIDE a layer."""
+    layers = [(2048, 2560, 2560), (2048, 5120, 5120)]        # 100 + 400 tiles ... + a third below
+    res = _run(layers + [(2048, 2560, 2560)], 0, seed=70)     # 600 tiles: the cut is inside the third layer
+    for q, (dw, rw, db, rb) in enumerate(res):
+        _check(dw, rw, f"hybrid layer {q} dw")
+        _check(db, rb, f"hybrid layer {q} dbias", rel=1e-4)
+
+
 def test_without_bias_and_eligibility_query():
     C = _C()
     (dw, rw, db, rb), = _run([(2048, 512, 256)], 0, with_bias=False)
