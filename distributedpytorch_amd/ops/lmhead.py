@@ -2,8 +2,8 @@
 
 GPT-2's tied head is ``logits = h @ wte^T`` with 50,304 (padded) columns: at 32 x 1024 tokens the logits are
 1.65 G elements - 3.3 GB in bf16, and past the 2^30-element range of the kernels' 32-bit gather offsets, which used to cap
-the per-GPU batch at 20 sequences.  Here the rows are processed in chunks (default 8,192: the shape ``gemm_wide.hip`` is
-tuned on): per chunk the head GEMM writes an 824 MB logits block, the one-pass cross-entropy kernel
+the per-GPU batch at 20 sequences.  Here the rows are processed in chunks (default 16,384: whole rounds of ``gemm_wide.hip``
+tiles): per chunk the head GEMM writes an 824 MB logits block, the one-pass cross-entropy kernel
 (``csrc/loss.hip ce_fused_kernel``) turns it into its own gradient in place, and the chunk's two backward GEMMs - input
 gradient and weight gradient - run at once, while the block is still hot; then the block is reused.  So forward ALSO
 produces ``d loss / d h`` and ``d loss / d wte`` (for an upstream gradient of 1, as the one-pass kernel does), and
@@ -27,6 +27,10 @@ from . import _ext
 from . import sink as _sink
 
 _FORCE_ROWS = int(os.environ.get("DPA_LMHEAD_CHUNK_ROWS", "0"))      # > 0: always chunk, by this many rows
+# chunk length when the logits do not fit one operand: 16,384 rows x 768 -> 50,304 is the shape whose tiles make whole rounds
+# on 256 CUs (the input gradient: 64 x 4 tiles of 256 x 192); 8,192-row chunks ran it at half a round
+# (GPT-2 at 32 x 1024: profiles/r3/lmhead_chunk_ab.txt)
+_CHUNK_ROWS = int(os.environ.get("DPA_LMHEAD_CHUNK_DEFAULT", "16384"))
 LIMIT = 1 << 30                                                     # elements of one operand of the GEMM kernels
 
 
@@ -37,7 +41,7 @@ def chunk_rows_for(rows: int, cols: int) -> int:
     if rows * cols < LIMIT:
         return 0
     fit = max(1024, (LIMIT - 1) // cols // 1024 * 1024)
-    return min(8192, fit)
+    return min(_CHUNK_ROWS, fit)
 
 
 class _LMHeadLossFn(torch.autograd.Function):
