@@ -21,6 +21,7 @@
 // Workgroup = 4 waves; each wave owns 32 queries (fwd, dQ) or 32 keys (dK/dV); K/V (or
 // Q/dO) tiles of 64 rows are staged through LDS and shared by the 4 waves.
 #include <math.h>
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -131,8 +132,8 @@ __device__ __forceinline__ void store_T(unsigned short* __restrict__ dst, const 
 }
 
 // ------------------------------------------------------------------------------ forward
-template <int DH, bool DROP>
-__global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_fwd_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
+template <int DH, bool DROP, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
                                                        float* __restrict__ lse, int T, int H, float c_log2, AttnDrop drop) {
     constexpr int KK = DH / 16, DI = DH / 32, TB = tile_bytes<DH>();
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TB];
@@ -180,13 +181,17 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_fwd_kernel(const u
                 S[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<DH>(Ks, 32 * t2 + ql, kk, h), qf[kk], S[t2], 0, 0, 0);
         }
         const bool diag = (j * TILE + TILE - 1) > qw0;             // tile may contain keys > some query of the wave
+        // VALU diet (the kernel is bound by the vector ALU at head dimension 64, not by the MFMAs): the running maximum is
+        // taken over the RAW scores and scaled once per row (c_log2 > 0), the scale itself rides the exponent's fused
+        // multiply-add - 32 multiplications per tile gone -, and the accumulator is rescaled only in tiles that raise some
+        // row's maximum (after the first few tiles of a row almost none do: wave-uniform branch).
         float mx = NEG_BIG;
         if (diag) {                                              // wave-uniform: only these tiles pay for the mask
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float s = S[t2][r] * c_log2;
+                    float s = S[t2][r];
                     if ((j * TILE + 32 * t2 + acc_row(r, h)) > qc) s = NEG_BIG;
                     S[t2][r] = s;
                     mx = fmaxf(mx, s);
@@ -195,26 +200,30 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_fwd_kernel(const u
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float s = S[t2][r] * c_log2;
-                    S[t2][r] = s;
-                    mx = fmaxf(mx, s);
-                }
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[t2][r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx);
-        const float alpha = fast_exp2(m - mn);
+        const float mn = fmaxf(m, mx * c_log2);                  // (masked scores: -1e30 * c stays hugely negative)
+        const bool grew = mn > m;
         float rsum = 0.f;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = fast_exp2(S[t2][r] - mn);
+                const float p = fast_exp2(fmaf(S[t2][r], c_log2, -mn));
                 S[t2][r] = p;
                 rsum += p;
             }
         rsum += __shfl_xor(rsum, 32, 64);
-        l = l * alpha + rsum;
+        if (__any(grew)) {
+            const float alpha = fast_exp2(m - mn);
+            l *= alpha;
+#pragma unroll
+            for (int di = 0; di < DI; ++di)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) O[di][r] *= alpha;
+        }
+        l += rsum;
         m = mn;
         if (DROP) {                                    // the normaliser l sees the undropped probabilities
             const float ks = 1.f / (1.f - drop.p);
@@ -224,10 +233,6 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_fwd_kernel(const u
 #pragma unroll
                 for (int r = 0; r < 16; ++r) S[t2][r] *= attn_keep(drop, rb, j * TILE + 32 * t2 + acc_row(r, h), ks);
         }
-#pragma unroll
-        for (int di = 0; di < DI; ++di)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) O[di][r] *= alpha;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -468,11 +473,19 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_q_kernel(const
 template <int DH>
 void launch_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, AttnDrop drop, hipStream_t st) {
     const float c_log2 = (1.0f / sqrtf((float)DH)) * 1.4426950408889634f;   // 1/sqrt(DH) * log2(e)
+    // Without dropout the head-dimension-64 kernel also builds into 128 registers (four waves per SIMD instead of three).
+    // Measured (profiles/r3/attn_occ_ab.txt): 48.6-49.3 us against 47.2-48.5 us at 16 x 12 x 1024, so the three-wave build
+    // stays the default; DPA_ATTN_FWD_OCC=4 selects the other one.
+    static const bool occ4 = [] { const char* e = getenv("DPA_ATTN_FWD_OCC"); return e && atoi(e) == 4; }();
+    constexpr int OCC = DH == 64 ? 2 : 1;
     if (drop.p > 0.f)
-        hipLaunchKernelGGL((attn_fwd_kernel<DH, true>), dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
+        hipLaunchKernelGGL((attn_fwd_kernel<DH, true, OCC>), dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
+                           (unsigned short*)out, lse, T, H, c_log2, drop);
+    else if (DH == 64 && occ4)
+        hipLaunchKernelGGL((attn_fwd_kernel<DH, false, DH == 64 ? 4 : OCC>), dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
                            (unsigned short*)out, lse, T, H, c_log2, drop);
     else
-        hipLaunchKernelGGL((attn_fwd_kernel<DH, false>), dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
+        hipLaunchKernelGGL((attn_fwd_kernel<DH, false, OCC>), dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
                            (unsigned short*)out, lse, T, H, c_log2, drop);
 }
 
