@@ -252,6 +252,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const unsigned short
 }
 
 // ------------------------------------------------------------------------------ dK / dV (key-stationary)
+// (206 registers: two waves per SIMD.  Forced into 168 for three - __launch_bounds__(256, 3), 124 bytes of scratch inside the
+// loop - the pair of backward kernels went from 168 to 221 us at 16 x 12 x 1024: profiles/r3/attn_bwd_kv_occ_ab.txt.)
 template <int DH, bool DROP>
 __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_kv_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ d_o,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_kv_kernel(cons
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int qr = 32 * t2 + acc_row(r, h);
-                    const float p = (jq * TILE + qr >= key) ? fast_exp2(S[r] * c_log2 - lse_s[qr]) : 0.f;
+                    const float p = fast_exp2((jq * TILE + qr >= key) ? S[r] * c_log2 - lse_s[qr] : NEG_BIG);   // a select, not a branch
                     S[r] = p;
                     dP[r] = p * (dP[r] - del_s[qr]) * scale;
                 }
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_q_kernel(const
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kg = kt0 + acc_row(r, h);
-                    const float p = (kg <= qc) ? fast_exp2(St[r] * c_log2 - lse_q) : 0.f;
+                    const float p = fast_exp2((kg <= qc) ? St[r] * c_log2 - lse_q : NEG_BIG);   // a select, not a branch
                     dPt[r] = p * (dPt[r] - del_q) * scale;
                 }
             } else {
