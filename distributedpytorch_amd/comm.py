@@ -300,14 +300,23 @@ class Communicator:
         pipeline engine issues at every stage boundary) and an ``ncclCommSplit`` into two halves with an all-reduce
         inside each.  ``strict``: raise on failure (no c10d to fall back to); else every rank drops to c10d when ANY
         rank failed (decided by an all-reduce on the control plane, so the ranks cannot disagree)."""
-        ok, why = True, ""
         W, r = self.world_size, self.rank
-        try:
+        dev = self.device
+
+        def spin(comm, ticket, what):
+            import time
+            t0 = time.monotonic()
+            while not comm.query(ticket):
+                if time.monotonic() - t0 > _SELFTEST_TIMEOUT_S:
+                    raise TimeoutError(f"{what} did not complete in {_SELFTEST_TIMEOUT_S:.0f} s")
+                time.sleep(0.0005)
+            comm.wait(ticket)
+
+        def phase_allreduce():
             if self.native is None:
                 raise RuntimeError("no native communicator on this rank")
             if _SELFTEST_TIMEOUT_S <= 0:
                 raise TimeoutError("self-test disabled by DPA_COMM_SELFTEST_TIMEOUT=0 (fallback rehearsal)")
-            dev = self.device
             for n in (1024, 8 * 2 ** 20):
                 t = torch.full((n,), float(r + 1), dtype=torch.float32, device=dev)
                 self._watch(self.native.all_reduce(t, 0), f"all-reduce of {n} floats")
@@ -315,84 +324,90 @@ class Communicator:
                 got = t[:: max(1, n // 64)].float().cpu()
                 if not bool((got == want).all()):
                     raise RuntimeError(f"native all-reduce returned {float(got[0])}, expected {want}")
-            if W > 1:
-                n = 4096
-                t = torch.full((n,), float(r + 1), dtype=torch.float32, device=dev)
-                self._watch(self.native.broadcast(t, W - 1), "broadcast")
-                if float(t[-1]) != float(W):
-                    raise RuntimeError(f"native broadcast returned {float(t[-1])}, expected {float(W)}")
-                t.fill_(float(r + 1))
-                self._watch(self.native.reduce(t, 0), "reduce")
-                if r == 0 and float(t[0]) != W * (W + 1) / 2.0:
-                    raise RuntimeError(f"native reduce returned {float(t[0])}")
-                src = torch.arange(W * 8, dtype=torch.float32, device=dev) + 1000.0 * r
-                piece = torch.empty(8, dtype=torch.float32, device=dev)
-                self._watch(self.native.reduce_scatter(piece, src), "reduce-scatter")
-                want = torch.arange(8, dtype=torch.float32) + 8.0 * r
-                want = want * W + 1000.0 * (W * (W - 1) / 2.0)
-                if not torch.equal(piece.cpu(), want):
-                    raise RuntimeError("native reduce-scatter returned wrong values")
-                full = torch.empty(W * 8, dtype=torch.float32, device=dev)
-                self._watch(self.native.all_gather(full, piece), "all-gather")
-                q = (r + 1) % W                    # the neighbour's piece: (arange(8) + 8 q) * W + 1000 * W (W - 1) / 2
-                if float(full[8 * q]) != 8.0 * q * W + 1000.0 * (W * (W - 1) / 2.0):
-                    raise RuntimeError("native all-gather returned wrong values")
-                # neighbour ring through grouped send/recv: rank r -> r + 1, r - 1 -> r, one group per rank
-                out = torch.full((n,), float(r), dtype=torch.bfloat16, device=dev)
-                inp = torch.full((n,), -1.0, dtype=torch.bfloat16, device=dev)
-                self._watch(self.native.batch_p2p([(True, out, (r + 1) % W), (False, inp, (r - 1) % W)]), "grouped send/recv ring")
-                if float(inp[0]) != float((r - 1) % W) or float(inp[-1]) != float((r - 1) % W):
-                    raise RuntimeError(f"native send/recv ring delivered {float(inp[0])}, expected {float((r - 1) % W)}")
-                # sub-communicators (what build_grid makes for DP x PP): [0, W/2) and [W/2, W) ...
-                half = W // 2
-                lo = r < half
-                sub = self.native.split(0 if lo else 1, r, r if lo else r - half, half if lo else W - half)
-                t = torch.ones(256, dtype=torch.float32, device=dev)
-                sub_w = half if lo else W - half
-                tk = sub.all_reduce(t, 0)
-                import time
-                t0 = time.monotonic()
-                while not sub.query(tk):
-                    if time.monotonic() - t0 > _SELFTEST_TIMEOUT_S:
-                        raise TimeoutError("all-reduce on an ncclCommSplit sub-communicator did not complete")
-                    time.sleep(0.0005)
-                sub.wait(tk)
-                if float(t[0]) != float(sub_w):
-                    raise RuntimeError(f"sub-communicator all-reduce returned {float(t[0])}, expected {sub_w}")
-                sub.synchronize()
-                del sub
-                if W > 2:
-                    # ... and a split that leaves the last rank out (NCCL_SPLIT_NOCOLOR: build_grid's idle ranks)
-                    idle = r == W - 1
-                    sub = self.native.split(-1 if idle else 0, 0 if idle else r, 0 if idle else r, 1 if idle else W - 1)
-                    if idle != (sub is None):
-                        raise RuntimeError("ncclCommSplit with NOCOLOR returned a communicator to the wrong ranks")
-                    if sub is not None:
-                        t = torch.ones(256, dtype=torch.float32, device=dev)
-                        tk = sub.all_reduce(t, 0)
-                        t0 = time.monotonic()
-                        while not sub.query(tk):
-                            if time.monotonic() - t0 > _SELFTEST_TIMEOUT_S:
-                                raise TimeoutError("all-reduce on the NOCOLOR-split sub-communicator did not complete")
-                            time.sleep(0.0005)
-                        sub.wait(tk)
-                        if float(t[0]) != float(W - 1):
-                            raise RuntimeError(f"NOCOLOR-split all-reduce returned {float(t[0])}, expected {W - 1}")
-                        sub.synchronize()
-                        del sub
-        except Exception as e:  # noqa: BLE001
-            ok, why = False, f"{type(e).__name__}: {e}"
-        if strict:
-            if not ok:
-                raise RuntimeError(f"native RCCL communicator failed its self-test: {why}")
-            return
-        all_ok = ok
-        if W > 1:
-            # agreement on the control plane: host tensor under gloo, device tensor when c10d itself runs on RCCL
+
+        def phase_collectives_p2p():
+            n = 4096
+            t = torch.full((n,), float(r + 1), dtype=torch.float32, device=dev)
+            self._watch(self.native.broadcast(t, W - 1), "broadcast")
+            if float(t[-1]) != float(W):
+                raise RuntimeError(f"native broadcast returned {float(t[-1])}, expected {float(W)}")
+            t.fill_(float(r + 1))
+            self._watch(self.native.reduce(t, 0), "reduce")
+            if r == 0 and float(t[0]) != W * (W + 1) / 2.0:
+                raise RuntimeError(f"native reduce returned {float(t[0])}")
+            src = torch.arange(W * 8, dtype=torch.float32, device=dev) + 1000.0 * r
+            piece = torch.empty(8, dtype=torch.float32, device=dev)
+            self._watch(self.native.reduce_scatter(piece, src), "reduce-scatter")
+            want = torch.arange(8, dtype=torch.float32) + 8.0 * r
+            want = want * W + 1000.0 * (W * (W - 1) / 2.0)
+            if not torch.equal(piece.cpu(), want):
+                raise RuntimeError("native reduce-scatter returned wrong values")
+            full = torch.empty(W * 8, dtype=torch.float32, device=dev)
+            self._watch(self.native.all_gather(full, piece), "all-gather")
+            q = (r + 1) % W                    # the neighbour's piece: (arange(8) + 8 q) * W + 1000 * W (W - 1) / 2
+            if float(full[8 * q]) != 8.0 * q * W + 1000.0 * (W * (W - 1) / 2.0):
+                raise RuntimeError("native all-gather returned wrong values")
+            # neighbour ring through grouped send/recv: rank r -> r + 1, r - 1 -> r, one group per rank
+            out = torch.full((n,), float(r), dtype=torch.bfloat16, device=dev)
+            inp = torch.full((n,), -1.0, dtype=torch.bfloat16, device=dev)
+            self._watch(self.native.batch_p2p([(True, out, (r + 1) % W), (False, inp, (r - 1) % W)]), "grouped send/recv ring")
+            if float(inp[0]) != float((r - 1) % W) or float(inp[-1]) != float((r - 1) % W):
+                raise RuntimeError(f"native send/recv ring delivered {float(inp[0])}, expected {float((r - 1) % W)}")
+
+        def phase_split():
+            # sub-communicators (what build_grid makes for DP x PP): [0, W/2) and [W/2, W) ...
+            half = W // 2
+            lo = r < half
+            sub = self.native.split(0 if lo else 1, r, r if lo else r - half, half if lo else W - half)
+            t = torch.ones(256, dtype=torch.float32, device=dev)
+            sub_w = half if lo else W - half
+            spin(sub, sub.all_reduce(t, 0), "all-reduce on an ncclCommSplit sub-communicator")
+            if float(t[0]) != float(sub_w):
+                raise RuntimeError(f"sub-communicator all-reduce returned {float(t[0])}, expected {sub_w}")
+            sub.synchronize()
+            del sub
+            if W > 2:
+                # ... and a split that leaves the last rank out (NCCL_SPLIT_NOCOLOR: build_grid's idle ranks)
+                idle = r == W - 1
+                sub = self.native.split(-1 if idle else 0, 0 if idle else r, 0 if idle else r, 1 if idle else W - 1)
+                if idle != (sub is None):
+                    raise RuntimeError("ncclCommSplit with NOCOLOR returned a communicator to the wrong ranks")
+                if sub is not None:
+                    t = torch.ones(256, dtype=torch.float32, device=dev)
+                    spin(sub, sub.all_reduce(t, 0), "all-reduce on the NOCOLOR-split sub-communicator")
+                    if float(t[0]) != float(W - 1):
+                        raise RuntimeError(f"NOCOLOR-split all-reduce returned {float(t[0])}, expected {W - 1}")
+                    sub.synchronize()
+                    del sub
+
+        def everyone(ok: bool) -> bool:
+            """Agreement on the control plane (never on the layer under test): the c10d group - host tensor under gloo,
+            device tensor when c10d itself runs on RCCL - or the TCP store of a c10d-free communicator."""
+            if W <= 1:
+                return ok
+            if self._static is not None:
+                return self._agree(ok)
             on_dev = self._c10d_backend() == "nccl"
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if on_dev else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-            all_ok = bool(int(flag.item()) == 1)
+            return bool(int(flag.item()) == 1)
+
+        # Phase by phase, with an agreement after each: a rank that failed a check must not leave the others alone in
+        # the next COLLECTIVE of the layer under test (ncclCommSplit blocks on the host: no watchdog could end it).
+        ok, why, all_ok = True, "", True
+        phases = [phase_allreduce] + ([phase_collectives_p2p, phase_split] if W > 1 else [])
+        for phase in phases:
+            try:
+                phase()
+            except Exception as e:  # noqa: BLE001
+                ok, why = False, f"{type(e).__name__}: {e}"
+            all_ok = everyone(ok)
+            if not all_ok:
+                break
+        if strict:
+            if not all_ok:
+                raise RuntimeError(f"native RCCL communicator failed its self-test: {why or 'on another rank'}")
+            return
         if not all_ok:
             import sys
             print(f"[comm] rank {self.global_rank}: native RCCL layer failed its self-test"

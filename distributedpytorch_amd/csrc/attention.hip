@@ -98,6 +98,7 @@ __device__ __forceinline__ bf16x8 pack_regs(const floatx16& x, int s) {   // reg
 
 // 2^x as ONE v_exp_f32: arguments here are <= 0 (score minus running max / log-sum-exp), so exp2f's denormal
 // and overflow range handling (5 extra VALU instructions per element) buys nothing; very negative -> 0.
+typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // Attention dropout (GPT-2's attn_pdrop): element (b, head, q, k) of the probability matrix is kept or dropped by the
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_kv_kernel(cons
         if (tid < TILE) {
             const int qi = jq * TILE + tid;                       // queries past T: lse = +big makes their probabilities 0
             lse_s[tid] = qi < T ? lse_b[qi] * 1.4426950408889634f : 1.0e30f;
-            del_s[tid] = qi < T ? del_b[qi] : 0.f;
+            del_s[tid] = qi < T ? del_b[qi] * scale : 0.f;          // pre-scaled: dS = p * (dP * scale - delta * scale)
         }
         __syncthreads();
         if (jq + 1 < nq) {
@@ -325,23 +326,37 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_kv_kernel(cons
                     const float kp = attn_keep(drop, ((uint64_t)(b * H + head) * T + qg) * T, keyc, ks);
                     const float p = (jq * TILE + qr >= key) ? fast_exp2(S[r] * c_log2 - lse_s[qr]) : 0.f;
                     S[r] = p * kp;
-                    dP[r] = p * (dP[r] * kp - del_s[qr]) * scale;
-                }
-            } else if (qt0 < kw0 + 31) {                                 // diagonal half tile: causal mask
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int qr = 32 * t2 + acc_row(r, h);
-                    const float p = fast_exp2((jq * TILE + qr >= key) ? S[r] * c_log2 - lse_s[qr] : NEG_BIG);   // a select, not a branch
-                    S[r] = p;
-                    dP[r] = p * (dP[r] - del_s[qr]) * scale;
+                    dP[r] = p * (dP[r] * kp * scale - del_s[qr]);
                 }
             } else {
+                // two query rows at a time through the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32): the kernel is bound by
+                // the vector ALU, and rows r, r + 1 of an accumulator are neighbours in the query index (acc_row)
+                const float2v c2 = {c_log2, c_log2}, sc2 = {scale, scale};
+                const float* ls = lse_s + 32 * t2 + 4 * h;
+                const float* dl = del_s + 32 * t2 + 4 * h;
+                if (qt0 < kw0 + 31) {                                      // diagonal half tile: causal mask (wave-uniform)
+                    const int qk = key - (jq * TILE + 32 * t2 + 4 * h);    // row acc_row(r, 0) is visible iff >= qk
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int qr = 32 * t2 + acc_row(r, h);
-                    const float p = fast_exp2(S[r] * c_log2 - lse_s[qr]);
-                    S[r] = p;
-                    dP[r] = p * (dP[r] - del_s[qr]) * scale;
+                    for (int r = 0; r < 16; r += 2) {
+                        const int a = acc_row(r, 0);
+                        float2v e = float2v{S[r], S[r + 1]} * c2 - *(const float2v*)(ls + a);
+                        e.x = a >= qk ? e.x : NEG_BIG;                     // selects, not branches
+                        e.y = a + 1 >= qk ? e.y : NEG_BIG;
+                        const float2v p = {fast_exp2(e.x), fast_exp2(e.y)};
+                        const float2v ds = p * (float2v{dP[r], dP[r + 1]} * sc2 - *(const float2v*)(dl + a));
+                        S[r] = p.x; S[r + 1] = p.y;
+                        dP[r] = ds.x; dP[r + 1] = ds.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const int a = acc_row(r, 0);
+                        const float2v e = float2v{S[r], S[r + 1]} * c2 - *(const float2v*)(ls + a);
+                        const float2v p = {fast_exp2(e.x), fast_exp2(e.y)};
+                        const float2v ds = p * (float2v{dP[r], dP[r + 1]} * sc2 - *(const float2v*)(dl + a));
+                        S[r] = p.x; S[r + 1] = p.y;
+                        dP[r] = ds.x; dP[r + 1] = ds.y;
+                    }
                 }
             }
 #pragma unroll
@@ -439,18 +454,28 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_q_kernel(const
                     const float p = (kg <= qc) ? fast_exp2(St[r] * c_log2 - lse_q) : 0.f;
                     dPt[r] = p * (dPt[r] * attn_keep(drop, rb, min(kg, T - 1), ks) - del_q) * scale;
                 }
-            } else if (kt0 + 31 > qw0) {                          // diagonal half tile: causal mask
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kg = kt0 + acc_row(r, h);
-                    const float p = fast_exp2((kg <= qc) ? St[r] * c_log2 - lse_q : NEG_BIG);   // a select, not a branch
-                    dPt[r] = p * (dPt[r] - del_q) * scale;
-                }
             } else {
+                const float2v c2 = {c_log2, c_log2}, sc2 = {scale, scale}, l2 = {lse_q, lse_q}, d2 = {del_q * scale, del_q * scale};
+                if (kt0 + 31 > qw0) {                               // diagonal half tile: causal mask (wave-uniform)
+                    const int kq = qc - (kt0 + 4 * h);              // key row acc_row(r, 0) is visible iff <= kq
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = fast_exp2(St[r] * c_log2 - lse_q);
-                    dPt[r] = p * (dPt[r] - del_q) * scale;
+                    for (int r = 0; r < 16; r += 2) {               // packed fp32 pairs, as in the key-stationary kernel
+                        const int a = acc_row(r, 0);
+                        float2v e = float2v{St[r], St[r + 1]} * c2 - l2;
+                        e.x = a <= kq ? e.x : NEG_BIG;
+                        e.y = a + 1 <= kq ? e.y : NEG_BIG;
+                        const float2v p = {fast_exp2(e.x), fast_exp2(e.y)};
+                        const float2v ds = p * (float2v{dPt[r], dPt[r + 1]} * sc2 - d2);
+                        dPt[r] = ds.x; dPt[r + 1] = ds.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const float2v e = float2v{St[r], St[r + 1]} * c2 - l2;
+                        const float2v p = {fast_exp2(e.x), fast_exp2(e.y)};
+                        const float2v ds = p * (float2v{dPt[r], dPt[r + 1]} * sc2 - d2);
+                        dPt[r] = ds.x; dPt[r + 1] = ds.y;
+                    }
                 }
             }
 #pragma unroll
