@@ -22,6 +22,7 @@
 // Q/dO) tiles of 64 rows are staged through LDS and shared by the 4 waves.
 #include <math.h>
 #include <stdlib.h>
+#include <atomic>
 #include "common.h"
 #include "kernels.h"
 
@@ -99,7 +100,31 @@ __device__ __forceinline__ bf16x8 pack_regs(const floatx16& x, int s) {   // reg
 // 2^x as ONE v_exp_f32: arguments here are <= 0 (score minus running max / log-sum-exp), so exp2f's denormal
 // and overflow range handling (5 extra VALU instructions per element) buys nothing; very negative -> 0.
 typedef float float2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// The two halves of a wave hold the two halves of a query's row statistics: combine lane i with lane i ^ 32 through
+// gfx950's v_permlane32_swap (a vector-ALU instruction) instead of __shfl_xor's ds_bpermute, which is an LDS round trip
+// with a wait in the middle of every tile's dependency chain.  swap(x, x) returns (low half twice, high half twice).
+// (The results are copied into scalars before the bit cast: __builtin_bit_cast applied to `r[1]` itself reads element 0 with
+// this compiler - the sum came out as 2 * r[0].)
+__device__ __forceinline__ void xhalf_swap(float x, float& lo, float& hi) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned a = r.x, b = r.y;
+    lo = __builtin_bit_cast(float, a);
+    hi = __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float xhalf_max(float x) {
+    float lo, hi;
+    xhalf_swap(x, lo, hi);
+    return fmaxf(lo, hi);
+}
+__device__ __forceinline__ float xhalf_sum(float x) {
+    float lo, hi;
+    xhalf_swap(x, lo, hi);
+    return lo + hi;
+}
 
 // Attention dropout (GPT-2's attn_pdrop): element (b, head, q, k) of the probability matrix is kept or dropped by the
 // counter hash of common.h at index ((b * H + head) * T + q) * T + k of the stream (seed, offset) - the same pure
@@ -203,7 +228,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const unsigned short
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[t2][r]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xhalf_max(mx);
         const float mn = fmaxf(m, mx * c_log2);                  // (masked scores: -1e30 * c stays hugely negative)
         const bool grew = mn > m;
         float rsum = 0.f;
@@ -215,7 +240,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const unsigned short
                 S[t2][r] = p;
                 rsum += p;
             }
-        rsum += __shfl_xor(rsum, 32, 64);
+        rsum = xhalf_sum(rsum);
         if (__any(grew)) {
             const float alpha = fast_exp2(m - mn);
             l *= alpha;
@@ -245,6 +270,137 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const unsigned short
                                                                     O[di], 0, 0, 0);
             }
     }
+    if (q < T) {
+        const float inv = 1.f / l;
+        store_T<DH>(out + ((long)(b * T + q) * H + head) * DH, O, inv, h);
+        if (h == 0) lse[((long)b * H + head) * T + q] = (m + log2f(l)) * 0.6931471805599453f;
+    }
+}
+
+// ------------------------------------------------------------------------------ forward, software-pipelined (DH = 64, no dropout)
+// OPT-IN, and slower as measured (see launch_fwd): kept as the record of the experiment the round-2 review asked for.
+// The kernel above runs score MFMAs -> softmax -> P V MFMAs one after the other inside a wave and leaves the overlap to
+// the three waves of a SIMD; removing a fifth of its vector-ALU work changed nothing (profiles/r3/attn_fwd_lm_ab.txt), and
+// an ablation (profiles/r3/attn_fwd_ablation.txt) shows every part's time adding up: no softmax -9.7 us of 46.5, no score
+// MFMAs -9.7, no P V -7.0, no staging -10.2, no exponentials -0.8.  Here a wave works on HALF tiles (32 keys) and keeps two score blocks: the MFMAs
+// of half tile g + 1 are issued in front of the softmax of half tile g and run in the matrix pipe under its vector work;
+// the P V MFMAs of g run under the softmax of g + 1.  K lives in a ring of three LDS tiles (half tile 2j + 2 needs tile
+// j + 1 while tile j is still being read), V in two, so ONE barrier per 64 keys covers both the hand-over of the freshly
+// written tiles and the reuse of the oldest ones (the kernel above needs two).  Half tiles also make the causal cut
+// exact: a wave visits key blocks 0 .. qw0 / 32 and only the last one is masked.
+__device__ __forceinline__ floatx16 score_half(const unsigned char* Kt, int row0, int ql, int h, const bf16x8 (&qf)[4]) {
+    floatx16 S;
+    zero16(S);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<64>(Kt, row0 + ql, kk, h), qf[kk], S, 0, 0, 0);
+    return S;
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
+                                                               float* __restrict__ lse, int T, int H, float c_log2) {
+    constexpr int DH = 64, KK = 4, DI = 2, TB = tile_bytes<64>();
+    __shared__ __attribute__((aligned(16))) unsigned char smem[5 * TB];     // K ring of 3, V ring of 2: 40 KiB
+    unsigned char* const Kr = smem;
+    unsigned char* const Vr = smem + 3 * TB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane & 31, h = lane >> 5;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int q0 = (gridDim.z - 1 - blockIdx.z) * 128, qw0 = q0 + 32 * wave, q = qw0 + ql;
+    const int qc = q < T ? q : T - 1;
+    const long rs = 3L * H * DH;
+    const unsigned short* base = qkv + (long)b * T * rs + head * DH;
+    const unsigned short* kbase = base + (long)H * DH;
+    const unsigned short* vbase = base + 2L * H * DH;
+
+    bf16x8 qf[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) qf[kk] = *(const bf16x8*)(base + (long)qc * rs + 16 * kk + 8 * h);
+    floatx16 O[DI];
+#pragma unroll
+    for (int di = 0; di < DI; ++di) zero16(O[di]);
+    float m = NEG_BIG, l = 0.f;
+    int ntiles = (q0 + 128) / TILE;
+    if (ntiles > (T + TILE - 1) / TILE) ntiles = (T + TILE - 1) / TILE;
+    int gmax = qw0 / 32;                                            // the wave's last (diagonal) half tile ...
+    if (gmax > 2 * ntiles - 1) gmax = 2 * ntiles - 1;               // ... (ragged T: waves whose queries are all past T)
+
+    u32x4 pk[2], pv[2];
+    fetch_tile<DH>(kbase, rs, 0, T - 1, tid, pk);
+    fetch_tile<DH>(vbase, rs, 0, T - 1, tid, pv);
+    stash_tile<DH>(Kr, tid, pk);
+    stash_tile<DH>(Vr, tid, pv);
+    if (ntiles > 1) {
+        fetch_tile<DH>(kbase, rs, TILE, T - 1, tid, pk);
+        stash_tile<DH>(Kr + TB, tid, pk);
+    }
+    __syncthreads();
+    if (ntiles > 2) fetch_tile<DH>(kbase, rs, 2 * TILE, T - 1, tid, pk);     // K of tile j + 2 and V of tile j + 1 ride in registers
+    if (ntiles > 1) fetch_tile<DH>(vbase, rs, TILE, T - 1, tid, pv);
+    floatx16 Sc = score_half(Kr, 0, ql, h, qf), Sn;
+
+    // softmax of one half tile + its P V products; `diag`: the wave's own key block, masked above the diagonal
+#define DPA_ATTN_HALF(G, VT, ROW0)                                                                                     \
+    {                                                                                                                  \
+        float mx = NEG_BIG;                                                                                            \
+        if ((G) == gmax) {                                                                                             \
+            const int lim = qc - 32 * (G) - 4 * h;                   /* row acc_row(r, 0) is visible iff <= lim */     \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                           \
+                Sc[r] = acc_row(r, 0) <= lim ? Sc[r] : NEG_BIG;                                                        \
+                mx = fmaxf(mx, Sc[r]);                                                                                 \
+            }                                                                                                          \
+        } else {                                                                                                       \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) mx = fmaxf(mx, Sc[r]);                                      \
+        }                                                                                                              \
+        mx = xhalf_max(mx);                                                                        \
+        const float mn = fmaxf(m, mx * c_log2);                                                                        \
+        const bool grew = mn > m;                                                                                      \
+        float rsum = 0.f;                                                                                              \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                               \
+            const float p = fast_exp2(fmaf(Sc[r], c_log2, -mn));                                                       \
+            Sc[r] = p;                                                                                                 \
+            rsum += p;                                                                                                 \
+        }                                                                                                              \
+        rsum = xhalf_sum(rsum);                                                                              \
+        if (__any(grew)) {                                                                                             \
+            const float alpha = fast_exp2(m - mn);                                                                     \
+            l *= alpha;                                                                                                \
+            _Pragma("unroll") for (int di = 0; di < DI; ++di)                                                          \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) O[di][r] *= alpha;                                      \
+        }                                                                                                              \
+        l += rsum;                                                                                                     \
+        m = mn;                                                                                                        \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                                \
+            const bf16x8 pb = pack_regs(Sc, s);                                                                        \
+            _Pragma("unroll") for (int di = 0; di < DI; ++di)                                                          \
+                O[di] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<DH>(VT, (ROW0) + 16 * s + 4 * h, 32 * di, lane), pb,  \
+                                                                O[di], 0, 0, 0);                                       \
+        }                                                                                                              \
+    }
+
+    int kcur = 0, knext = 1, kfree = 2;                             // ring slots of K tiles j, j + 1, j + 2
+    for (int j = 0; j < ntiles; ++j) {
+        if (j > 0) __syncthreads();                                 // tiles written in step j - 1 are visible, tiles read in it are free
+        if (j + 2 < ntiles) stash_tile<DH>(Kr + kfree * TB, tid, pk);
+        if (j + 1 < ntiles) stash_tile<DH>(Vr + ((j + 1) & 1) * TB, tid, pv);
+        if (j + 3 < ntiles) fetch_tile<DH>(kbase, rs, (j + 3) * TILE, T - 1, tid, pk);
+        if (j + 2 < ntiles) fetch_tile<DH>(vbase, rs, (j + 2) * TILE, T - 1, tid, pv);
+        const int g0 = 2 * j;
+        if (g0 <= gmax) {                                           // wave-uniform
+            const unsigned char* Kt = Kr + kcur * TB;
+            const unsigned char* Vt = Vr + (j & 1) * TB;
+            if (g0 + 1 <= gmax) Sn = score_half(Kt, 32, ql, h, qf);                 // half tile 2j + 1, under the softmax below
+            DPA_ATTN_HALF(g0, Vt, 0)
+            if (g0 + 1 <= gmax) {
+                Sc = Sn;
+                if (g0 + 2 <= gmax) Sn = score_half(Kr + knext * TB, 0, ql, h, qf);   // half tile 2j + 2 (tile j + 1)
+                DPA_ATTN_HALF(g0 + 1, Vt, 32)
+                Sc = Sn;
+            }
+        }
+        const int t = kcur; kcur = knext; knext = kfree; kfree = t;
+    }
+#undef DPA_ATTN_HALF
     if (q < T) {
         const float inv = 1.f / l;
         store_T<DH>(out + ((long)(b * T + q) * H + head) * DH, O, inv, h);
@@ -412,7 +568,7 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_q_kernel(const
 #pragma unroll
         for (int j = 0; j < 8; ++j) del_q += (float)dof[kk][j] * (float)of[j];
     }
-    del_q += __shfl_xor(del_q, 32, 64);
+    del_q = xhalf_sum(del_q);
     if (h == 0 && q < T) delta[((long)b * H + head) * T + q] = del_q;
     const float lse_q = lse[((long)b * H + head) * T + qc] * 1.4426950408889634f;
     floatx16 dQt[DI];
@@ -497,6 +653,8 @@ __global__ __launch_bounds__(256, DH == 64 ? 2 : 1) void attn_bwd_q_kernel(const
 // kernel as slow as a chip an eighth the size on the heaviest eighth.  With (head, batch) fastest every XCD sees every
 // block index equally often, heaviest blocks are dispatched first, and - 8 | H * B permitting - the blocks of one
 // (batch, head) land on one XCD, whose L2 then holds that head's K and V once.
+std::atomic<int> g_fwd_pipe{[] { const char* e = getenv("DPA_ATTN_FWD_PIPE"); return e ? atoi(e) : 0; }()};
+
 template <int DH>
 void launch_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, AttnDrop drop, hipStream_t st) {
     const float c_log2 = (1.0f / sqrtf((float)DH)) * 1.4426950408889634f;   // 1/sqrt(DH) * log2(e)
@@ -505,6 +663,14 @@ void launch_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, Att
     // stays the default; DPA_ATTN_FWD_OCC=4 selects the other one.
     static const bool occ4 = [] { const char* e = getenv("DPA_ATTN_FWD_OCC"); return e && atoi(e) == 4; }();
     constexpr int OCC = DH == 64 ? 2 : 1;
+    // The software-pipelined kernel is opt-in (DPA_ATTN_FWD_PIPE=1 or set_attention_fwd_pipe): measured 54-55 us against
+    // 47-48 us at 16 x 12 x 1024 and 194 against 172 us at 4 x 12 x 4096 (profiles/r3/attn_fwd_pipe_ab.txt).
+    const bool pipe = g_fwd_pipe.load(std::memory_order_relaxed) != 0;
+    if (DH == 64 && pipe && !(drop.p > 0.f)) {
+        hipLaunchKernelGGL(attn_fwd_pipe_kernel, dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
+                           (unsigned short*)out, lse, T, H, c_log2);
+        return;
+    }
     if (drop.p > 0.f)
         hipLaunchKernelGGL((attn_fwd_kernel<DH, true, OCC>), dim3(H, B, (T + 127) / 128), dim3(256), 0, st, (const unsigned short*)qkv,
                            (unsigned short*)out, lse, T, H, c_log2, drop);
@@ -531,6 +697,8 @@ void launch_bwd(const void* qkv, const void* out, const void* dout, const float*
 }
 
 }  // namespace
+
+void set_attention_fwd_pipe(int on) { g_fwd_pipe.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 void attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int Dh, float drop_p, uint64_t seed,
                    uint64_t offset, hipStream_t st) {

@@ -1166,6 +1166,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("set_wide_gemm_min_tiles", [](int64_t n) { dpa::set_wide_gemm_min_tiles((int)n); });
     m.def("set_wide_gemm_splitk", [](int64_t n) { dpa::set_wide_gemm_splitk((int)n); });
     m.def("set_wide_gemm_bn", [](int64_t n) { dpa::set_wide_gemm_bn((int)n); });
+    m.def("set_attention_fwd_pipe", [](bool on) { dpa::set_attention_fwd_pipe(on ? 1 : 0); });
     m.def("wide_gemm_min_tiles", []() { return (int64_t)dpa::wide_gemm_min_tiles(); });
     bind_transformer(m);
     bind_rccl(m);

@@ -236,6 +236,7 @@ void embedding_bwd(const int64_t* tok, const void* dy, float* dwte, float* dwpe,
 // causal flash attention, qkv packed [B, T, 3, H, D] bf16, D = 64
 // drop_p > 0: attention dropout, element (b, h, q, k) kept by the counter hash at index ((b*H + h)*T + q)*T + k of the
 // stream (seed, offset) - dropout_mask() with n = B*H*T*T reproduces the mask
+void set_attention_fwd_pipe(int on);   // 1 = the software-pipelined half-tile forward kernel (D = 64, no dropout); default 0 / DPA_ATTN_FWD_PIPE
 void attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int D, float drop_p, uint64_t seed,
                    uint64_t offset, hipStream_t st);
 void attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,

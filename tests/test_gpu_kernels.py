@@ -642,6 +642,30 @@ def test_causal_attention_fwd_bwd(B, T, H, D):
         _close(g[:, :, i], gr[:, :, i], 3e-2, 3e-2, "attention " + name)
 
 
+@pytest.mark.parametrize("B,T,H", [(1, 1, 1), (1, 65, 2), (2, 200, 2), (2, 256, 3), (1, 1000, 2), (2, 1024, 4)])
+def test_causal_attention_pipelined_forward_kernel(B, T, H):
+    """The opt-in software-pipelined forward kernel (csrc/attention.hip ``attn_fwd_pipe_kernel``: half tiles, scores of
+    the next half tile issued in front of the softmax of the current one, K ring of three LDS tiles) against the fp32
+    oracle and against the default kernel's log-sum-exp, ragged lengths included."""
+    C, D = _C(), 64
+    qkv = _rand_bf16(B, T, 3 * H * D, seed=51).view(B, T, 3, H, D)
+    out0, lse0 = C.attention_fwd(qkv)
+    C.set_attention_fwd_pipe(True)
+    try:
+        out1, lse1 = C.attention_fwd(qkv)
+        torch.cuda.synchronize()
+    finally:
+        C.set_attention_fwd_pipe(False)
+    q, k, v = qkv.float().cpu().permute(2, 0, 3, 1, 4)
+    att = (q @ k.transpose(-2, -1)) / math.sqrt(D)
+    att = att.masked_fill(~torch.ones(T, T, dtype=torch.bool).tril(), float("-inf"))
+    ref = (att.softmax(dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, T, H * D)
+    _close(out1.reshape(B, T, H * D), ref, 2e-2, 2e-2, "pipelined attention out")
+    _close(lse1, torch.logsumexp(att, dim=-1), 1e-3, 1e-3, "pipelined attention lse")
+    _close(lse1, lse0, 1e-4, 1e-4, "pipelined vs default lse")
+    _close(out1.reshape(B, T, H * D), out0.reshape(B, T, H * D), 1e-2, 1e-2, "pipelined vs default out")
+
+
 @pytest.mark.parametrize("B,T,H,D", [(2, 200, 3, 64), (1, 256, 2, 64), (1, 130, 2, 128)])
 def test_causal_attention_with_dropout_matches_masked_reference(B, T, H, D):
     """Attention dropout drawn INSIDE the three kernels (csrc/attention.hip ``AttnDrop``): the kept / dropped pattern is
