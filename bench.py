@@ -94,21 +94,6 @@ def peak_flops(dtype: str) -> float:
     return 2.5e15 if dtype == "bf16" else 157.3e12
 
 
-def load_baseline_own(model: str, per_gpu_batch: int):
-    """This framework's own recorded 1-GPU throughput (BASELINE_MEASURED.json, key "own"), for the efficiency field."""
-    path = os.path.join(ROOT, "BASELINE_MEASURED.json")
-    try:
-        with open(path) as f:
-            entry = json.load(f).get("own", {}).get(model)
-        if isinstance(entry, dict) and str(per_gpu_batch) in entry.get("by_batch", {}):
-            entry = entry["by_batch"][str(per_gpu_batch)]
-        if isinstance(entry, dict) and int(entry.get("batch", per_gpu_batch)) == per_gpu_batch:
-            return float(entry["1"])
-    except Exception:  # noqa: BLE001
-        return None
-    return None
-
-
 def _rccl_version():
     """RCCL's own version number (ncclGetVersion through the extension; torch's record as a fallback)."""
     try:
@@ -311,11 +296,7 @@ def main():
         if result.get("flops_per_item"):
             # model FLOP utilisation against the dense MFMA peak of the GPUs used (no sparsity figures)
             out["mfu"] = round(value * result["flops_per_item"] / (world * peak_flops(dtype)), 4)
-        base1 = load_baseline_own(args.model, pgb)
-        if base1 and not (args.pipeline and args.pipeline > 1):
-            # weak-scaling efficiency against this framework's own recorded 1-GPU number (BASELINE_MEASURED.json "own")
-            from distributedpytorch_amd.metrics import scaling_efficiency
-            out["scaling_efficiency_vs_recorded_1gpu"] = round(scaling_efficiency(value, base1, world), 4)
+        # (scaling efficiency is for whoever runs N = 1, 2, 4, 8 to compute from the per-N values: scripts/scale_table.py)
         for k in ("allreduce_bytes_per_step", "allreduce_calls_per_step", "breakdown_ms"):
             if result.get(k) is not None:
                 out[k] = result[k]
