@@ -123,6 +123,12 @@ def init_process_group(backend: str = "auto", init_method: Optional[str] = None,
     comm._timeout_s = timeout_s
     if native_wanted and (comm.world_size > 1 or _FORCE_COLLECTIVES):
         comm.attach_native()
+    elif os.environ.get("DPA_FAKE_NATIVE", "0") == "1" and comm._c10d_backend() == "gloo" and comm.world_size > 1:
+        # rehearsal of the native layer's Python side at world size > 1 without several GPUs (utils/fake_native.py):
+        # the same self-test, the same call paths, the data carried by gloo
+        from .utils.fake_native import GlooNative
+        comm.native = GlooNative(None)
+        comm._selftest_native(strict=False)
     if native_wanted and comm.native is None and comm._c10d_backend() != "nccl" and \
             (comm.world_size > 1 or _FORCE_COLLECTIVES):
         # the native layer is not there (never created, or it failed its self-test on some rank): device traffic
@@ -260,7 +266,8 @@ class Communicator:
         process group).  Sub-communicator: ``ncclCommSplit`` of the parent's native communicator."""
         from .ops import _ext
         C = _ext.load()
-        if self.device is None or self.device.type != "cuda":
+        host_ok = parent is not None and getattr(parent.native, "accepts_host", False)     # utils/fake_native.py (tests)
+        if (self.device is None or self.device.type != "cuda") and not host_ok:
             raise RuntimeError("the native RCCL communicator needs a GPU device")
         if parent is not None:
             if parent.native is None:
@@ -542,7 +549,10 @@ class Communicator:
         return _PeerWork(self.peer, self.peer.all_reduce(tensor, 1.0, self.grad_wire == "bf16"))
 
     def _on_native(self, *tensors: torch.Tensor) -> bool:
-        return self.native is not None and all(t.is_cuda and t.is_contiguous() for t in tensors)
+        if self.native is None:
+            return False
+        host_ok = getattr(self.native, "accepts_host", False)        # utils/fake_native.py (tests) takes CPU tensors too
+        return all((t.is_cuda or host_ok) and t.is_contiguous() for t in tensors)
 
     def _native_all_reduce(self, tensor: torch.Tensor, op):
         code = {dist.ReduceOp.SUM: 0, dist.ReduceOp.MAX: 1, dist.ReduceOp.MIN: 2}.get(op)

@@ -118,6 +118,7 @@ def dp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, buc
     torch.save({"losses": losses, "params": {n: p.detach().cpu().clone() for n, p in model.named_parameters()},
                 "buckets": len(dp.buckets), "calls": dp.stats["allreduce_calls"], "opt": opt.state_dict(),
                 "peer_launches": int(comm.peer.launches) if comm.peer is not None else 0,
+                "native_calls": list(getattr(comm.native, "calls", [])),       # utils/fake_native.py rehearsals
                 "momentum_numel": 0 if opt.momentum_buf is None else opt.momentum_buf.numel()},
                os.path.join(out_dir, f"final_{global_rank}.pt"))
     comm.barrier()
@@ -204,7 +205,11 @@ def pp_worker(local_rank, global_rank, world_size, url, model_name, out_dir, sta
             opt.step()
             if loss is not None:
                 losses.append(float(loss))
-        torch.save({"losses": losses, "slots": slots}, os.path.join(out_dir, f"final_r{replica}_s{stage}.pt"))
+        torch.save({"losses": losses, "slots": slots,
+                    "native_calls": {"world": list(getattr(world.native, "calls", [])),
+                                     "pp": list(getattr(pp_comm.native, "calls", [])) if pp_comm is not None else [],
+                                     "dp": list(getattr(dp_comm.native, "calls", [])) if dp_comm is not None else []}},
+                   os.path.join(out_dir, f"final_r{replica}_s{stage}.pt"))
         from ..checkpoint import save_checkpoint
         save_checkpoint(os.path.join(out_dir, f"ckpt_r{replica}.pt"), stage_mod, opt, 0, comm=dp_comm, pipeline_comm=pp_comm)
     world.barrier()

@@ -670,3 +670,24 @@ def test_sharded_optimizer_on_the_gpu_matches_the_replicated_one(tmp_path, model
     # mnist: fp32 kernels (atomics order only); tiny_resnet: bf16 + ReLU bits, compared in aggregate
     assert (num / den) ** 0.5 < (1e-4 if model_name == "mnist" else 2e-2), (num / den) ** 0.5
     assert z[0]["losses"][-1] < z[0]["losses"][0]
+
+
+def test_two_ranks_on_the_gpu_reduce_through_the_native_layers_python_side(tmp_path, monkeypatch):
+    """As test_two_ranks_share_the_gpu..., with utils/fake_native.GlooNative installed as ``Communicator.native``
+    (DPA_FAKE_NATIVE=1): DEVICE buckets of the HIP engine go through ``_native_all_reduce`` / ``_NativeWork`` - the path
+    of a multi-GPU job - after the native self-test's collective phases have run at world size 2."""
+    monkeypatch.setenv("DPA_FAKE_NATIVE", "1")
+    test_two_ranks_share_the_gpu_and_match_the_cpu_reference(tmp_path, "mnist")
+    calls = torch.load(tmp_path / "final_1.pt", weights_only=True)["native_calls"]
+    assert calls[:7] == ["all_reduce", "all_reduce", "broadcast", "reduce", "reduce_scatter", "all_gather", "batch_p2p"]
+    assert calls.count("all_reduce") >= 2 + 3
+
+
+def test_pipeline_stages_on_the_gpu_exchange_through_grouped_native_p2p(tmp_path, monkeypatch):
+    """As test_pipeline_stages_share_the_gpu..., with the stand-in native layer: activations and gradients of the HIP
+    engine leave as DEVICE tensors through ``Communicator.batch_p2p`` -> ``native.batch_p2p`` (the grouped ncclSend /
+    ncclRecv form), on sub-communicators that build_grid made with ``native.split``."""
+    monkeypatch.setenv("DPA_FAKE_NATIVE", "1")
+    test_pipeline_stages_share_the_gpu_and_match_the_unsplit_cpu_model(tmp_path, "mnist", 2, 4, 16)
+    calls = torch.load(tmp_path / "final_r0_s1.pt", weights_only=True)["native_calls"]
+    assert calls["pp"].count("batch_p2p") >= 3 * 4
