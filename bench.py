@@ -255,8 +255,11 @@ def main():
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
         elapsed = communicator.all_reduce_scalar(elapsed, "max")
-        layer = "native (csrc/rccl_comm.cpp)" if communicator.native is not None else \
-            ("c10d" if torch.distributed.is_initialized() else "none (single process, no collectives)")
+        if getattr(communicator.native, "accepts_host", False):
+            layer = "native layer's Python side over a gloo stand-in (utils/fake_native.py): a rehearsal, not RCCL"
+        else:
+            layer = "native (csrc/rccl_comm.cpp)" if communicator.native is not None else \
+                ("c10d" if torch.distributed.is_initialized() else "none (single process, no collectives)")
         no_comm = communicator.native is None and not torch.distributed.is_initialized()
         communicator.check_peer()     # a bounded poll of the peer-mapped kernel that ran out would have left wrong sums behind
         if no_comm:

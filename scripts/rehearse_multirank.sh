@@ -19,6 +19,17 @@ run dp2_r50_sharded 2 --batch 32 --steps 4 --warmup 2 --shard-optimizer
 # gradient buckets through the one-kernel all-reduce over hipIpc-mapped peer memory (two ranks of one GPU map each other)
 DPA_PEER_CHUNK_MB=8 run dp2_r50_ipc 2 --batch 32 --steps 4 --warmup 2 --allreduce ipc
 grep -o '"allreduce": "[^"]*"' gpurun_out/rehearse/dp2_r50_ipc.log | tail -1
+# the same flows through the NATIVE layer's Python side (utils/fake_native.py: RcclComm's interface, data over gloo): self-test
+# phases at world size > 1, buckets through _native_all_reduce, ZeRO-1 on native reduce / broadcast, and - for 4 and 8 ranks -
+# what the driver's N = 4 / 8 runs do before the first step.  "comm_layer" must read native in these lines.
+DPA_FAKE_NATIVE=1 run dp2_r50_nat 2 --batch 32 --steps 4 --warmup 2
+grep -o '"comm_layer": "[^"]*"' gpurun_out/rehearse/dp2_r50_nat.log | tail -1
+DPA_FAKE_NATIVE=1 run dp4_r50_nat 4 --batch 16 --steps 3 --warmup 1
+DPA_FAKE_NATIVE=1 run dp8_mnist_nat 8 --model mnist --steps 30 --warmup 5
+DPA_FAKE_NATIVE=1 run dp2_gpt2_nat 2 --model gpt2 --batch 2 --steps 4 --warmup 2
+DPA_FAKE_NATIVE=1 run dp2_r50_sharded_nat 2 --batch 32 --steps 4 --warmup 2 --shard-optimizer
+DPA_FAKE_NATIVE=1 run pp2_mnist_nat 2 --model mnist --pipeline 2 --steps 20 --warmup 5
+DPA_FAKE_NATIVE=1 run pp2xdp2_mnist_nat 4 --model mnist --pipeline 2 --steps 10 --warmup 3
 run pp2_mnist 2 --model mnist --pipeline 2 --steps 20 --warmup 5
 run pp4_r152 4 --model resnet152 --pipeline 4 --batch 32 --steps 3 --warmup 1
 # the RCCL path (native communicator, every bucket all-reduced for real) at world size 1
