@@ -37,6 +37,12 @@ MAX_PROBLEMS = 8                                   # csrc/kernels.h WGRAD_WIDE_M
 _query_cache: Dict[Tuple[int, int, int], Tuple[bool, int]] = {}
 
 
+def _graph_task_id() -> int:
+    """Id of the running backward pass (-1 outside one; 0 on a torch without the query: the guard is then inert)."""
+    fn = getattr(torch._C, "_current_graph_task_id", None)
+    return int(fn()) if fn is not None else 0
+
+
 def query(rows: int, cout: int, cin: int) -> Tuple[bool, int]:
     """(can and should this Linear-shaped problem go to the wide kernel, its number of 256 x 256 tiles)."""
     key = (rows, cout, cin)
@@ -56,11 +62,23 @@ class WgradBatcher:
         self.tiles = 0
         self.rows = -1
         self.callback_queued = False
+        self.task_id = -1                      # autograd graph task the held problems (and the queued callback) belong to
         self.launches = 0                      # statistics: launches / problems so far
         self.problems = 0
+        self.dropped = 0                       # problems of a backward pass that died before its end-of-backward callback
 
     def add(self, x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, dbias: Optional[torch.Tensor], params, tiles: int) -> None:
         rows = x.shape[0]
+        tid = _graph_task_id()
+        if tid != self.task_id:
+            # another backward pass than the one the state belongs to: that one ended without its callback (an exception
+            # inside backward).  Its held problems are gradients of a pass the caller has abandoned - adding them to the
+            # buffers of THIS pass would be wrong - and its callback will never run.
+            if self.items:
+                self.dropped += len(self.items)
+                self.items, self.tiles, self.rows = [], 0, -1
+            self.callback_queued = False
+            self.task_id = tid
         if self.items and (rows != self.rows or len(self.items) >= MAX_PROBLEMS):
             self.flush()
         self.items.append((x, dy, dw, dbias, list(params)))
