@@ -63,6 +63,8 @@ def parse():
     p.add_argument("--allreduce", default=None, choices=["ring", "direct", "ipc"],
                    help="RCCL's ring, the one-shot direct algorithm over grouped send/recv, or ONE kernel over hipIpc-mapped peer memory (csrc/peer_allreduce.hip)")
     p.add_argument("--grad-wire", default=None, choices=["fp32", "bf16"], help="direct all-reduce: gradient format on the links")
+    p.add_argument("--run-ahead", type=int, default=2,
+                   help="steps the host may be ahead of the GPU (utils/pacer.py; 0 = unbounded, the behaviour until the last day of round 3)")
     return p.parse_args()
 
 
@@ -239,8 +241,13 @@ def main():
             return loss
 
         from distributedpytorch_amd.utils.gcguard import GCGuard
+        from distributedpytorch_amd.utils.pacer import StepPacer
+        # the host stays at most two steps ahead of the GPU (utils/pacer.py: unbounded run-ahead has a slow mode here);
+        # the small CNN's 0.13 ms steps are paced every 64th step
+        pacer = StepPacer(device, depth=0 if args.run_ahead == 0 else args.run_ahead, stride=64 if args.model == "mnist" else 1)
         for _ in range(args.warmup):
             step()
+            pacer.step()
         timer.summary()                      # drop the warm-up's samples
         dp.stats["allreduce_calls"] = dp.stats["allreduce_bytes"] = 0
         # the collector runs at a fixed step period, the same step on every rank (as in train.py): a generation-2
@@ -252,6 +259,7 @@ def main():
             for _ in range(args.steps):
                 loss = step()
                 guard.step()
+                pacer.step()
             communicator.barrier()
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
@@ -279,7 +287,11 @@ def main():
                   "config": dict(cfg, parallelism=f"dp{world}", per_gpu_batch=batch,
                                  buckets=len(dp.buckets), optimizer=f"fused SGD momentum {momentum}", comm_layer=layer,
                                  allreduce=algo, gpu_max_hw_queues=int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-                                 rccl_version=_rccl_version())}
+                                 rccl_version=_rccl_version(),
+                                 host_run_ahead_steps=args.run_ahead,
+                                 max_memory_allocated_gb=round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
+                                 max_memory_reserved_gb=round(torch.cuda.max_memory_reserved(device) / 1e9, 2),
+                                 device_allocs=int(torch.cuda.memory_stats(device).get("num_device_alloc", 0)))}
 
     if rank == 0:
         elapsed = result["elapsed"]

@@ -555,9 +555,13 @@ def run_pipeline_bench(args, world: _comm.Communicator, device: torch.device) ->
     from ..metrics import PhaseTimer
     eng.timer = PhaseTimer(device)       # a few dozen HIP events per step: forward / backward / p2p per micro-batch
 
+    from ..utils.pacer import StepPacer
+    pacer = StepPacer(device, depth=getattr(args, "run_ahead", 2))       # utils/pacer.py: the host at most two steps ahead
+
     def step():
         loss = eng.train_step(batch, x if eng.first else None, y if eng.last else None)
         opt.step()
+        pacer.step()
         return loss
 
     for _ in range(args.warmup):

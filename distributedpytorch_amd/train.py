@@ -24,6 +24,7 @@ from .parallel.dp import DataParallel
 from .parallel.flat import FlatParams
 from .parallel.pp import PipelineStage, build_stage_module, partition_balanced, param_costs
 from .utils.gcguard import GCGuard
+from .utils.pacer import StepPacer
 
 
 def pick_device(cfg: TrainConfig, local_rank: int) -> torch.device:
@@ -142,6 +143,8 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
             opt.overlap_with_backward(dp)
         guard = GCGuard(period=500)      # collector at a fixed step period, the same step on every rank (utils/gcguard.py)
         guard.__enter__()
+        # the host may be two steps ahead of the GPU, not an epoch (utils/pacer.py); the graph-replayed small CNN every 64th step
+        pacer = StepPacer(device, depth=2, stride=64 if graphed is not None else 1)
         # --breakdown: HIP events around forward / backward / dp.finish() (= the part of the gradient reduction that backward
         # did NOT hide: "exposed communication") / optimizer; read back once per epoch, no host sync inside the step
         phases = dmetrics.PhaseTimer(device, enabled=cfg.breakdown)
@@ -166,6 +169,7 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                         loss.backward()
                     meter.update(x.shape[0])
                     guard.step()
+                    pacer.step()
                     continue
                 else:
                     with phases.phase("forward"):
@@ -186,6 +190,7 @@ def run_dp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                     opt.step()                           # fused: scale, momentum, update, bf16 shadow, zero grad
                 meter.update(x.shape[0])
                 guard.step()
+                pacer.step()
             last = float(epoch_loss / num_batches)
             comm.check_peer()                            # DPA_ALLREDUCE=ipc: no bounded poll of the peer-mapped kernel ran out
             breakdown = {k + "_ms": round(v, 4) for k, v in phases.summary().items()} if cfg.breakdown else {}
@@ -312,6 +317,7 @@ def run_mp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
         loss = None
         phases = dmetrics.PhaseTimer(device, enabled=cfg.breakdown)
         eng.timer = phases if cfg.breakdown else None          # forward / backward / p2p-wait per micro-batch (parallel/pp.py)
+        pacer = StepPacer(device, depth=2)                      # utils/pacer.py
         for epoch in range(start_epoch, cfg.epochs):
             meter.reset(); meter.start()
             for step, (x, y) in enumerate(loader):
@@ -322,6 +328,7 @@ def run_mp(local_rank: int, global_rank: int, world_size: int, cfg: TrainConfig)
                 with phases.phase("optimizer"):
                     opt.step()
                 meter.update(x.shape[0])
+                pacer.step()
             breakdown = {k + "_ms": round(v, 4) for k, v in phases.summary().items()} if cfg.breakdown else {}
             if breakdown:
                 print("[mp] stage %d replica %d epoch %d breakdown (mean ms per occurrence): %s" % (
