@@ -42,7 +42,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--model", default="resnet50", choices=["resnet50", "resnet152", "gpt2", "mnist", "tiny_resnet"])
     p.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 1024 resnet50 - the largest whose tensors stay under the kernels' 2^31-byte operand limit, "
-                        "+2.7 %% over 512 -, 512 resnet152, 16 gpt2: sized for 288 GB of HBM; BASELINE.md has 512 and 256 beside them, each "
+                        "+3-4 %% over 512 -, 1024 resnet152 too, 16 gpt2: sized for 288 GB of HBM; BASELINE.md has 512 and 256 beside them, each "
                         "against stock PyTorch at the SAME batch; 128/N mnist, the reference's global batch)")
     p.add_argument("--seq-len", type=int, default=1024)
     p.add_argument("--bucket-mb", type=float, default=32.0)
@@ -157,7 +157,7 @@ def main():
     else:
         if args.model in ("resnet50", "resnet152", "tiny_resnet"):
             from distributedpytorch_amd.models import resnet
-            batch = args.batch or {"resnet50": 1024, "resnet152": 512}.get(args.model, 256)
+            batch = args.batch or {"resnet50": 1024, "resnet152": 1024}.get(args.model, 256)
             if args.model == "tiny_resnet":
                 model = resnet.tiny_resnet(); hw, classes = 64, 16
             else:

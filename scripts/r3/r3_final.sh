@@ -17,7 +17,8 @@ run --steps 20 --warmup 5 || exit 1
 run --batch 256 --steps 20 --warmup 5 || exit 1
 run --model gpt2 --steps 20 --warmup 5 || exit 1
 run --model gpt2 --batch 8 --steps 20 --warmup 5 || exit 1
-run --model resnet152 --steps 10 --warmup 3 || exit 1
+run --model resnet152 --steps 8 --warmup 3 || exit 1
+run --model resnet152 --batch 512 --steps 10 --warmup 3 || exit 1
 run --model resnet152 --batch 256 --steps 10 --warmup 3 || exit 1
 run --model mnist --steps 500 --warmup 50 || exit 1
 done
