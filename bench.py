@@ -256,10 +256,12 @@ def main():
             communicator.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
+            c0 = time.process_time()
             for _ in range(args.steps):
                 loss = step()
                 guard.step()
                 pacer.step()
+            host_cpu = time.process_time() - c0        # CPU time of this process while enqueueing (all its threads)
             communicator.barrier()
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
@@ -289,6 +291,7 @@ def main():
                                  allreduce=algo, gpu_max_hw_queues=int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                                  rccl_version=_rccl_version(),
                                  host_run_ahead_steps=args.run_ahead,
+                                 host_cpu_ms_per_step=round(1000.0 * host_cpu / max(1, args.steps), 2),
                                  max_memory_allocated_gb=round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
                                  max_memory_reserved_gb=round(torch.cuda.max_memory_reserved(device) / 1e9, 2),
                                  device_allocs=int(torch.cuda.memory_stats(device).get("num_device_alloc", 0)))}

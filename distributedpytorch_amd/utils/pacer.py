@@ -18,7 +18,17 @@ from __future__ import annotations
 from collections import deque
 from typing import Optional
 
+import os
+import time
+
 import torch
+
+# How the host waits for the old event.  hipEventSynchronize spins on a core here, with or without the blocking-sync flag
+# (host CPU per step = wall time per step with both kinds: profiles/r3/pacer_wait_ab.txt), which is one busy core per rank for
+# nothing: the default polls event.query() and sleeps DPA_PACER_POLL_US (200) microseconds in between - the GPU has a whole
+# step queued behind the event, so a late wake-up of that size costs nothing.  DPA_PACER_WAIT=sync: the spinning wait.
+_WAIT = os.environ.get("DPA_PACER_WAIT", "poll").lower()
+_POLL_S = float(os.environ.get("DPA_PACER_POLL_US", "200")) * 1e-6
 
 
 class StepPacer:
@@ -42,9 +52,17 @@ class StepPacer:
         self._events.append(ev)
         if len(self._events) > self.depth:
             old = self._events.popleft()
-            old.synchronize()                      # host waits; the GPU still has `depth` paced steps queued behind it
+            self._wait(old)                        # host waits; the GPU still has `depth` paced steps queued behind it
             self.waits += 1
             self._pool.append(old)
+
+    @staticmethod
+    def _wait(ev) -> None:
+        if _WAIT == "sync":
+            ev.synchronize()
+            return
+        while not ev.query():
+            time.sleep(_POLL_S)
 
     def drain(self) -> None:
         while self._events:
