@@ -117,6 +117,8 @@ def init_process_group(backend: str = "auto", init_method: Optional[str] = None,
             os.environ.setdefault("WORLD_SIZE", str(world_size))
     if c10d_be == "nccl" and on_gpu:
         kwargs["device_id"] = device
+    if c10d_be == "gloo":
+        _pin_gloo_to_loopback()
     if not dist.is_initialized():
         dist.init_process_group(**kwargs)
     comm = Communicator(group=None, device=device)
@@ -137,6 +139,21 @@ def init_process_group(backend: str = "auto", init_method: Optional[str] = None,
     if _ALLREDUCE == "ipc" and on_gpu and comm.world_size > 1:
         comm.attach_peer()
     return comm
+
+
+def _pin_gloo_to_loopback() -> None:
+    """A single-node job (rendezvous at 127.0.0.1 / localhost) keeps gloo on the loopback interface: gloo otherwise looks
+    its interface up through the HOSTNAME, which need not resolve inside a container (it then falls back to loopback with a
+    warning on current builds, and failed outright on older ones).  Only when the user has not chosen an interface, the job
+    is local and ``lo`` exists; ``--ifname`` / GLOO_SOCKET_IFNAME always win."""
+    if os.environ.get("GLOO_SOCKET_IFNAME") or os.environ.get("MASTER_ADDR", "") not in ("127.0.0.1", "localhost", "::1"):
+        return
+    try:
+        import socket
+        if any(name == "lo" for _, name in socket.if_nameindex()):
+            os.environ["GLOO_SOCKET_IFNAME"] = "lo"
+    except OSError:
+        pass
 
 
 def init_native_group(init_method: str, rank: int, world_size: int, device: torch.device,
