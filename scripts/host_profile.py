@@ -44,10 +44,13 @@ for _ in range(3):
     step()
 torch.cuda.synchronize()
 pr = cProfile.Profile()
-pr.enable()
-for _ in range(steps):
-    step()
-    torch.cuda.synchronize()
-pr.disable()
+# backward on the calling thread, so that the Python backward functions show up in the profile (the engine's device thread
+# is invisible to cProfile)
+with torch.autograd.set_multithreading_enabled(False):
+    pr.enable()
+    for _ in range(steps):
+        step()
+        torch.cuda.synchronize()
+    pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats("tottime").print_stats(40)
